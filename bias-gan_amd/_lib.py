@@ -1,0 +1,119 @@
+"""ctypes binding of libbgamd.so (the C ABI declared in include/bgamd.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+fails, this raises.  The product path never routes through PyTorch ops or the
+CPU oracle for its arithmetic.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbgamd.so")
+
+BF16, F32 = 0, 1
+ABI_VERSION = 1
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
+                                     "dil", "ldx", "ldy")]
+
+
+class DwDesc(C.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "N", "H", "W", "C", "Ho", "Wo", "stride", "dil", "ldx", "ldy")]
+
+
+# name -> argtypes (restype is int for all but bg_last_error); mirrors include/bgamd.h
+_SIGS = {
+    "bg_abi_version": [],
+    "bg_conv2d_fwd": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bg_conv2d_bwd_data": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
+    "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bg_transpose_krsc": [c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
+    "bg_dwconv3x3_fwd": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
+    "bg_dwconv3x3_bwd_data": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
+    "bg_dwconv3x3_bwd_weight": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
+    "bg_norm_stats": [c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "bg_norm_finalize": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                         c_vp],
+    "bg_norm_eval_affine": [c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp],
+    "bg_norm_act_fwd": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_norm_act_bwd_reduce": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
+                               c_vp, c_vp, c_vp],
+    "bg_norm_bwd_finalize": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                             c_vp],
+    "bg_norm_act_bwd_apply": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
+                              c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_resize_bilinear_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_resize_bilinear_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_colsum": [c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp],
+    "bg_broadcast_rows": [c_i32, c_vp, c_f32, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp],
+    "bg_cast_rows": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp],
+    "bg_nchw_to_nhwc": [c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_nhwc_to_nchw": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "bg_fill_f32": [c_vp, c_f32, c_i64, c_vp],
+    "bg_axpy_rows": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp],
+    "bg_linear_head_fwd": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "bg_linear_head_bwd": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "bg_bce_logits": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp],
+    "bg_l1_loss_fwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
+    "bg_l1_loss_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
+    "bg_gp_penalty": [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp],
+    "bg_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32,
+                     c_f32, c_vp],
+    "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
+}
+EXPORTS = sorted(list(_SIGS) + ["bg_last_error"])
+
+_lib = None
+
+
+def load():
+    """Load libbgamd.so, failing loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"bias_gan_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no PyTorch/CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_i32
+    lib.bg_last_error.argtypes = []
+    lib.bg_last_error.restype = C.c_char_p
+    if lib.bg_abi_version() != ABI_VERSION:
+        raise RuntimeError("bias_gan_amd: libbgamd.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def dt(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an entry point on the current HIP stream; raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.bg_last_error().decode()}")

@@ -1,0 +1,592 @@
+// Dense convolution as implicit GEMM on the CDNA4 matrix cores.
+//
+//   forward   y[p, co]  = sum_{tap, ci} x[gather(p, tap), ci] * w[co, tap, ci]
+//   bwd_data  dx[p, ci] = sum_{tap, co} dy[scatter^-1(p, tap), co] * wt[ci, tap, co]
+//   bwd_wgt   dw[co, tap, ci] += sum_p dy[p, co] * x[gather(p, tap), ci]
+//
+// forward and bwd_data are ONE kernel (gemm_conv_kernel): a 128(out-channel) x
+// 128(pixel) tile per 256-thread workgroup, 4 waves as 2x2, each wave a 64x64
+// sub-tile of 4x4 MFMA 16x16 accumulators.  The out-channel side is the MFMA
+// A operand and the pixel side the B operand, so each lane ends up with 4
+// CONSECUTIVE output channels of one pixel -> 8/16-byte NHWC stores with no LDS
+// transpose.  Both operands are K-contiguous in memory (NHWC activations, KRSC /
+// CRSK weights), staged global -> registers -> LDS (the gather needs per-lane
+// zero fill, so no LDS-DMA), double-buffered, one barrier per K-step, with an
+// XOR swizzle on the 16-byte chunk index that makes the ds_read_b128 fragment
+// reads bank-conflict free for the lane groups of MI355X_MICROARCH.md (LDS).
+//
+// bwd_wgt (wgrad_kernel) reduces over pixels, which is the SLOW dimension of
+// both operands; tiles are staged pixel-major and the MFMA fragments are read
+// with the gfx950 transposing LDS read ds_read_b64_tr_b16 (bf16) or plain
+// ds_read_b32 columns (f32).  Pixels are split over blockIdx.y; partial tiles
+// are accumulated into the fp32 gradient with float atomics shaped as two
+// 128-byte row segments per wave instruction (32x32 accumulator layout).
+//
+// dtype BG_F32 runs the same kernels on the f32-input MFMA (16x16x4 / 32x32x2):
+// exact fp32 products and accumulation, used as the parity path.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 128;     // both tile edges
+constexpr int NTHREADS = 256;
+
+struct GemmConvParams {
+    const void* in;
+    const void* w;
+    void* out;
+    const float* bias;
+    int N, IH, IW, OH, OW;
+    int CK;  // reduction channels per tap (physical, multiple of VEC)
+    int NO;  // output channels (physical rows of w)
+    int ldi, ldo;
+    int KH, KW, stride, pad, dil;
+    int transposed;
+    long long M;  // N*OH*OW
+    int tiles_c, tiles_p;
+};
+
+template <int BKB>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    if constexpr (BKB == 64) {
+        return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
+    } else {
+        return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    }
+}
+
+// One K-slab of MFMAs for a wave: acc[i][j] += A_i * B_j over the BKB bytes of K.
+template <typename T, int BKB>
+__device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wave_c, int wave_p, int lane,
+                                         f32x4 (&acc)[4][4]) {
+    const int r16 = lane & 15, q = lane >> 4;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < BKB / 64; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(wave_c * 64 + i * 16 + r16, ks * 4 + q));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(wave_p * 64 + j * 16 + r16, ks * 4 + q));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < BKB / 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const float*>(sA + lds_off<BKB>(wave_c * 64 + i * 16 + r16, kk) + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const float*>(sB + lds_off<BKB>(wave_p * 64 + j * 16 + r16, kk) + q * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <typename T, int BKB>
+__global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int BK = BKB / sizeof(T);  // K elements per step
+    constexpr int CPR = BKB / 16;        // 16-byte chunks per tile row
+    constexpr int RPP = NTHREADS / CPR;  // rows per load pass
+    constexpr int NPASS = TILE / RPP;
+    constexpr int TILE_BYTES = TILE * BKB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [buf][A|B][TILE_BYTES]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_c = wave >> 1, wave_p = wave & 1;
+
+    // XCD-aware tile order: workgroups that share an XCD (same id % 8) walk
+    // consecutive tiles, and the channel tile varies fastest, so the blocks that
+    // re-read one pixel tile sit on one L2.
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tile_c = bid % P.tiles_c;
+    const int tile_p = bid / P.tiles_c;
+    const long long p_base = (long long)tile_p * TILE;
+    const int c_base = tile_c * TILE;
+
+    const int chunk = tid % CPR;
+    const int row0 = tid / CPR;
+    const int RS = P.KH * P.KW;
+
+    // per-thread row bookkeeping (fixed for the whole K loop)
+    long long pix_noff[NPASS];
+    int pix_h[NPASS], pix_w[NPASS];
+    bool pix_ok[NPASS];
+    long long w_roff[NPASS];
+    bool w_ok[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const long long p = p_base + row0 + i * RPP;
+        pix_ok[i] = p < P.M;
+        const long long pp = pix_ok[i] ? p : 0;
+        const int ohw = P.OH * P.OW;
+        const int n = (int)(pp / ohw);
+        const int rem = (int)(pp - (long long)n * ohw);
+        const int oh = rem / P.OW, ow = rem - oh * P.OW;
+        pix_noff[i] = (long long)n * P.IH * P.IW;
+        if (!P.transposed) {
+            pix_h[i] = oh * P.stride - P.pad;
+            pix_w[i] = ow * P.stride - P.pad;
+        } else {
+            pix_h[i] = oh + P.pad;
+            pix_w[i] = ow + P.pad;
+        }
+        const int co = c_base + row0 + i * RPP;
+        w_ok[i] = co < P.NO;
+        w_roff[i] = (long long)(w_ok[i] ? co : 0) * RS * P.CK;
+    }
+
+    const T* in = reinterpret_cast<const T*>(P.in);
+    const T* wt = reinterpret_cast<const T*>(P.w);
+
+    Chunk<T> ra[NPASS], rb[NPASS];
+
+    const int ksteps_per_tap = (P.CK + BK - 1) / BK;
+    const int KT = RS * ksteps_per_tap;
+
+    auto issue_loads = [&](int kt) {
+        const int tap = kt / ksteps_per_tap;
+        const int c = (kt - tap * ksteps_per_tap) * BK + chunk * VEC;
+        const int r = tap / P.KW, s = tap - r * P.KW;
+        const bool c_ok = c < P.CK;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            // weights (A operand)
+            if (w_ok[i] && c_ok) ra[i].load(wt + w_roff[i] + (long long)tap * P.CK + c);
+            else ra[i].zero();
+            // pixels (B operand)
+            int ih, iw;
+            bool ok = pix_ok[i] && c_ok;
+            if (!P.transposed) {
+                ih = pix_h[i] + r * P.dil;
+                iw = pix_w[i] + s * P.dil;
+                ok = ok && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
+            } else {
+                const int th = pix_h[i] - r * P.dil, tw = pix_w[i] - s * P.dil;
+                ok = ok && th >= 0 && tw >= 0;
+                ih = th / P.stride;
+                iw = tw / P.stride;
+                ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
+            }
+            if (ok) rb[i].load(in + (pix_noff[i] + (long long)ih * P.IW + iw) * P.ldi + c);
+            else rb[i].zero();
+        }
+    };
+    auto write_lds = [&](int buf) {
+        char* sA = smem + buf * 2 * TILE_BYTES;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = row0 + i * RPP;
+            ra[i].store(reinterpret_cast<T*>(sA + lds_off<BKB>(row, chunk)));
+            rb[i].store(reinterpret_cast<T*>(sB + lds_off<BKB>(row, chunk)));
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    write_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) issue_loads(kt + 1);  // global loads in flight under the MFMAs
+        const char* sA = smem + cur * 2 * TILE_BYTES;
+        mma_slab<T, BKB>(sA, sA + TILE_BYTES, wave_c, wave_p, lane, acc);
+        if (more) write_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: lane holds 4 consecutive out-channels of one pixel per accumulator
+    T* out = reinterpret_cast<T*>(P.out);
+    const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = p_base + wave_p * 64 + j * 16 + r16;
+        if (p >= P.M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
+            if (co >= P.NO) continue;
+            f32x4 v = acc[i][j];
+            if (P.bias) {
+                v[0] += P.bias[co + 0];
+                v[1] += P.bias[co + 1];
+                v[2] += P.bias[co + 2];
+                v[3] += P.bias[co + 3];
+            }
+            T* dst = out + p * P.ldo + co;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 o;
+                o[0] = (bf16_t)v[0];
+                o[1] = (bf16_t)v[1];
+                o[2] = (bf16_t)v[2];
+                o[3] = (bf16_t)v[3];
+                *reinterpret_cast<bf16x4*>(dst) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ wgrad ----
+struct WgradParams {
+    const void* x;
+    const void* dy;
+    float* dw;
+    int N, H, W, Ho, Wo;
+    int Ci, Co;  // physical channel counts
+    int ldx, ldy;
+    int KH, KW, stride, pad, dil;
+    long long M;
+    long long pix_per_split;  // multiple of 32
+    int tiles_co, tiles_ci;
+};
+
+constexpr int WG_PIX = 32;  // pixels per K-chunk
+
+template <typename T>
+__device__ __forceinline__ constexpr int wg_rowb() {
+    return TILE * (int)sizeof(T) + 64;  // +64 B pad: conflict-free transposed / column reads
+}
+
+template <typename T>
+__device__ __forceinline__ void wgrad_mma(const char* sA, const char* sB, int wave_m, int wave_n, int lane,
+                                          f32x16 (&acc)[2][2]) {
+    constexpr int ROWB = wg_rowb<T>();
+    if constexpr (sizeof(T) == 2) {
+        const int gi = lane >> 4, ii = lane & 15, qq = ii >> 2, pp = ii & 3;
+        const int cb = (gi & 1) * 16, h = gi >> 1;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+        for (int ks = 0; ks < WG_PIX / 16; ++ks) {
+            bf16x8 a[2], b[2];
+            const int rowp = ks * 16 + 8 * h + qq;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* pa = sA + rowp * ROWB + (wave_m * 64 + i * 32 + cb + 4 * pp) * 2;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * ROWB));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[i] = __builtin_bit_cast(bf16x8, t);
+                const char* pb = sB + rowp * ROWB + (wave_n * 64 + i * 32 + cb + 4 * pp) * 2;
+                s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb));
+                s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * ROWB));
+                s16x8 t2 = {lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+                b[i] = __builtin_bit_cast(bf16x8, t2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        const int r32 = lane & 31, h = lane >> 5;
+#pragma unroll 4
+        for (int kk = 0; kk < WG_PIX / 2; ++kk) {
+            float a[2], b[2];
+            const int rowp = 2 * kk + h;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float*>(sA + rowp * ROWB + (wave_m * 64 + i * 32 + r32) * 4);
+                b[i] = *reinterpret_cast<const float*>(sB + rowp * ROWB + (wave_n * 64 + i * 32 + r32) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int ROWB = wg_rowb<T>();
+    constexpr int CPR = TILE * sizeof(T) / 16;  // chunks per tile row (16 or 32)
+    constexpr int RPP = NTHREADS / CPR;         // rows per pass (16 or 8)
+    constexpr int NPASS = WG_PIX / RPP;         // 2 or 4
+    constexpr int TILE_BYTES = WG_PIX * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    const int RS = P.KH * P.KW;
+    int bid = blockIdx.x;
+    const int tile_ci = bid % P.tiles_ci;
+    bid /= P.tiles_ci;
+    const int tap = bid % RS;
+    const int tile_co = bid / RS;
+    const int r = tap / P.KW, s = tap - r * P.KW;
+    const int co_base = tile_co * TILE, ci_base = tile_ci * TILE;
+
+    const long long p_begin = (long long)blockIdx.y * P.pix_per_split;
+    long long p_end = p_begin + P.pix_per_split;
+    if (p_end > P.M) p_end = P.M;
+    if (p_begin >= p_end) return;  // uniform per block
+
+    const int chunk = tid % CPR, row0 = tid / CPR;
+    const bool co_ok = co_base + chunk * VEC < P.Co;
+    const bool ci_ok = ci_base + chunk * VEC < P.Ci;
+    const T* x = reinterpret_cast<const T*>(P.x);
+    const T* dy = reinterpret_cast<const T*>(P.dy);
+    const int ohw = P.Ho * P.Wo;
+
+    Chunk<T> ra[NPASS], rb[NPASS];
+    auto issue_loads = [&](long long pc) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const long long p = pc + row0 + i * RPP;
+            const bool pv = p < p_end;
+            if (pv && co_ok) ra[i].load(dy + p * P.ldy + co_base + chunk * VEC);
+            else ra[i].zero();
+            bool ok = pv && ci_ok;
+            long long off = 0;
+            if (ok) {
+                const int n = (int)(p / ohw);
+                const int rem = (int)(p - (long long)n * ohw);
+                const int oh = rem / P.Wo, ow = rem - oh * P.Wo;
+                const int ih = oh * P.stride - P.pad + r * P.dil;
+                const int iw = ow * P.stride - P.pad + s * P.dil;
+                ok = (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W;
+                off = (((long long)n * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC;
+            }
+            if (ok) rb[i].load(x + off);
+            else rb[i].zero();
+        }
+    };
+    auto write_lds = [&](int buf) {
+        char* sA = smem + buf * 2 * TILE_BYTES;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = row0 + i * RPP;
+            ra[i].store(reinterpret_cast<T*>(sA + row * ROWB + chunk * 16));
+            rb[i].store(reinterpret_cast<T*>(sB + row * ROWB + chunk * 16));
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue_loads(p_begin);
+    write_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (long long pc = p_begin; pc < p_end; pc += WG_PIX) {
+        const bool more = pc + WG_PIX < p_end;
+        if (more) issue_loads(pc + WG_PIX);
+        const char* sA = smem + cur * 2 * TILE_BYTES;
+        wgrad_mma<T>(sA, sA + TILE_BYTES, wave_m, wave_n, lane, acc);
+        if (more) write_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // accumulate: 32x32 accumulator layout: col = lane&31 (ci), row = (e&3)+8*(e>>2)+4*(lane>>5) (co)
+    const int c32 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci_base + wave_n * 64 + j * 32 + c32;
+            if (ci >= P.Ci) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co_base + wave_m * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co >= P.Co) continue;
+                atomicAdd(P.dw + ((long long)co * RS + tap) * P.Ci + ci, acc[i][j][e]);
+            }
+        }
+}
+
+// ---------------------------------------------------------- batched transpose
+template <typename T>
+__global__ void transpose_krsc_kernel(const T* __restrict__ src, T* __restrict__ dst, const long long* tbl) {
+    const long long* e = tbl + (long long)blockIdx.y * 5;
+    const long long so = e[0], dof = e[1], K = e[2], RS = e[3], C = e[4];
+    const long long total = K * RS * C;
+    // dst[c][rs][k] = src[k][rs][c]; index over dst so writes are coalesced
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long k = i % K;
+        const long long t = i / K;
+        const long long rs = t % RS;
+        const long long c = t / RS;
+        dst[dof + i] = src[so + (k * RS + rs) * C + c];
+    }
+}
+
+int check_conv_desc(const bg_conv_desc* d, const char* who) {
+    BG_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+    BG_CHECK_ARG(dtype_ok(d->dtype), "%s: bad dtype %d", who, d->dtype);
+    const int vec = dtype_vec(d->dtype);
+    BG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0,
+                 "%s: non-positive dimension", who);
+    BG_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->KH <= 7 && d->KW <= 7, "%s: kernel size %dx%d unsupported", who, d->KH,
+                 d->KW);
+    BG_CHECK_ARG(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "%s: bad stride/dil/pad", who);
+    BG_CHECK_ARG(d->Cin % vec == 0 && d->Cout % vec == 0,
+                 "%s: Cin=%d / Cout=%d must be multiples of %d (pad channels with zeros)", who, d->Cin, d->Cout, vec);
+    BG_CHECK_ARG(d->ldx >= d->Cin && d->ldy >= d->Cout && d->ldx % vec == 0 && d->ldy % vec == 0,
+                 "%s: bad pixel strides ldx=%d ldy=%d", who, d->ldx, d->ldy);
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+    BG_CHECK_ARG(ho == d->Ho && wo == d->Wo, "%s: output %dx%d does not match conv arithmetic %dx%d", who, d->Ho, d->Wo,
+                 ho, wo);
+    BG_CHECK_ARG((long long)d->N * d->H * d->W * d->ldx < (1LL << 40) && (long long)d->N * d->Ho * d->Wo < (1LL << 31),
+                 "%s: tensor too large", who);
+    return BG_OK;
+}
+
+template <typename T>
+int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
+    GemmConvParams P = P0;
+    P.tiles_c = (P.NO + TILE - 1) / TILE;
+    P.tiles_p = (int)((P.M + TILE - 1) / TILE);
+    const long long nblk = (long long)P.tiles_c * P.tiles_p;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        bg_set_error("conv: grid too large");
+        return BG_E_ARG;
+    }
+    // K-step width: 128-byte rows (BK = 64 bf16 / 32 f32) unless the padded
+    // reduction depth is smaller with 64-byte rows (e.g. Cin = 728 -> 736 vs 768).
+    const int bk64 = 64 / (int)sizeof(T), bk128 = 128 / (int)sizeof(T);
+    const int pad64 = (P.CK + bk64 - 1) / bk64 * bk64, pad128 = (P.CK + bk128 - 1) / bk128 * bk128;
+    const bool use128 = pad128 <= pad64 + pad64 / 32;
+    if (use128) {
+        const size_t sh = 2 * 2 * TILE * 128;
+        hipLaunchKernelGGL((gemm_conv_kernel<T, 128>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+    } else {
+        const size_t sh = 2 * 2 * TILE * 64;
+        hipLaunchKernelGGL((gemm_conv_kernel<T, 64>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+    }
+    BG_CHECK_LAUNCH("gemm_conv_kernel");
+    return BG_OK;
+}
+
+}  // namespace
+
+extern "C" int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                             void* stream) {
+    int rc = check_conv_desc(d, "bg_conv2d_fwd");
+    if (rc) return rc;
+    BG_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "bg_conv2d_fwd: null/unaligned pointer");
+    GemmConvParams P{};
+    P.in = x; P.w = w; P.out = y; P.bias = bias;
+    P.N = d->N; P.IH = d->H; P.IW = d->W; P.OH = d->Ho; P.OW = d->Wo;
+    P.CK = d->Cin; P.NO = d->Cout; P.ldi = d->ldx; P.ldo = d->ldy;
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
+    P.transposed = 0;
+    P.M = (long long)d->N * d->Ho * d->Wo;
+    if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
+    return launch_gemm_conv<float>(P, (hipStream_t)stream);
+}
+
+extern "C" int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream) {
+    int rc = check_conv_desc(d, "bg_conv2d_bwd_data");
+    if (rc) return rc;
+    BG_CHECK_ARG(dy && wt && dx && aligned16(dy) && aligned16(wt) && aligned16(dx),
+                 "bg_conv2d_bwd_data: null/unaligned pointer");
+    GemmConvParams P{};
+    P.in = dy; P.w = wt; P.out = dx; P.bias = nullptr;
+    P.N = d->N; P.IH = d->Ho; P.IW = d->Wo; P.OH = d->H; P.OW = d->W;
+    P.CK = d->Cout; P.NO = d->Cin; P.ldi = d->ldy; P.ldo = d->ldx;
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
+    P.transposed = 1;
+    P.M = (long long)d->N * d->H * d->W;
+    if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
+    return launch_gemm_conv<float>(P, (hipStream_t)stream);
+}
+
+extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                    void* stream) {
+    int rc = check_conv_desc(d, "bg_conv2d_bwd_weight");
+    if (rc) return rc;
+    BG_CHECK_ARG(x && dy && dw && aligned16(x) && aligned16(dy), "bg_conv2d_bwd_weight: null/unaligned pointer");
+    WgradParams P{};
+    P.x = x; P.dy = dy; P.dw = dw;
+    P.N = d->N; P.H = d->H; P.W = d->W; P.Ho = d->Ho; P.Wo = d->Wo;
+    P.Ci = d->Cin; P.Co = d->Cout; P.ldx = d->ldx; P.ldy = d->ldy;
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
+    P.M = (long long)d->N * d->Ho * d->Wo;
+    P.tiles_co = (d->Cout + TILE - 1) / TILE;
+    P.tiles_ci = (d->Cin + TILE - 1) / TILE;
+    const long long tiles = (long long)P.tiles_co * P.tiles_ci * d->KH * d->KW;
+    // enough pixel splits to put ~1024 workgroups on the chip, each with >= 256 pixels
+    long long splits = (1024 + tiles - 1) / tiles;
+    const long long max_splits = (P.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    P.pix_per_split = ((P.M + splits - 1) / splits + WG_PIX - 1) / WG_PIX * WG_PIX;
+    splits = (P.M + P.pix_per_split - 1) / P.pix_per_split;
+    BG_CHECK_ARG(tiles <= 0x7fffffffLL, "bg_conv2d_bwd_weight: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == BG_BF16) {
+        const size_t sh = 2 * 2 * WG_PIX * (TILE * 2 + 64);
+        hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)tiles, (unsigned)splits), dim3(NTHREADS), sh, st, P);
+    } else {
+        const size_t sh = 2 * 2 * WG_PIX * (TILE * 4 + 64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)tiles, (unsigned)splits), dim3(NTHREADS), sh, st, P);
+    }
+    BG_CHECK_LAUNCH("wgrad_kernel");
+    if (dbias) return bg_colsum(d->dtype, dy, d->ldy, P.M, d->Cout, 1, 1.0f, dbias, stream);
+    return BG_OK;
+}
+
+extern "C" int bg_transpose_krsc(int32_t dtype, const void* src, void* dst, const int64_t* tbl, int32_t n_layers,
+                                 int64_t max_elems, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && src && dst && tbl && n_layers > 0 && max_elems > 0, "bg_transpose_krsc: bad args");
+    BG_CHECK_ARG(n_layers <= 65535, "bg_transpose_krsc: too many layers");
+    long long bx = (max_elems + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BG_BF16)
+        hipLaunchKernelGGL((transpose_krsc_kernel<bf16_t>), dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, st,
+                           (const bf16_t*)src, (bf16_t*)dst, (const long long*)tbl);
+    else
+        hipLaunchKernelGGL((transpose_krsc_kernel<float>), dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, st,
+                           (const float*)src, (float*)dst, (const long long*)tbl);
+    BG_CHECK_LAUNCH("transpose_krsc_kernel");
+    return BG_OK;
+}

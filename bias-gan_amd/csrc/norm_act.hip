@@ -1,0 +1,444 @@
+// Normalisation + residual + LeakyReLU, forward and backward, NHWC.
+//
+// All kernels here are HBM-bound.  Element-wise passes move one 16-byte vector
+// per lane with lanes along channels (fully coalesced); per-channel reductions
+// keep fp32 partials in registers over a strip of rows, fold the row lanes of a
+// wave with shuffles and finish with fp64 atomics (so var = E[x^2]-E[x]^2 is
+// evaluated in double and the result does not depend on how rows were split).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------ column reduce --
+// block: 16 channel vectors (threadIdx.x & 15) x 16 row lanes (threadIdx.x >> 4)
+// grid : x = channel-vector blocks, y = row chunks inside a group, z = group
+enum { RED_STATS = 0, RED_BWD = 1, RED_COLSUM = 2 };
+
+struct RedParams {
+    const void* a;  // x (stats, colsum) | dy (bwd)
+    const void* b;  // y (bwd)
+    const void* c;  // x (bwd)
+    int lda, ldb, ldc;
+    const float* mean;
+    const float* rstd;
+    int act;
+    long long rows_per_group;
+    int rows_per_block;
+    int C;
+    double* o1;
+    double* o2;
+    float* of;  // colsum output
+    float scale;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvi = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int rlane = threadIdx.x >> 4;
+    const int c = cvi * VEC;
+    const bool c_ok = c < P.C;
+    const int g = blockIdx.z;
+    const long long r0 = (long long)blockIdx.y * P.rows_per_block;
+    long long r1 = r0 + P.rows_per_block;
+    if (r1 > P.rows_per_group) r1 = P.rows_per_group;
+    const long long gbase = (long long)g * P.rows_per_group;
+
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+    float mu[VEC], rs[VEC];
+    if (MODE == RED_BWD && c_ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            mu[e] = P.mean ? P.mean[(long long)g * P.C + c + e] : 0.f;
+            rs[e] = P.rstd ? P.rstd[(long long)g * P.C + c + e] : 1.f;
+        }
+    }
+    if (c_ok) {
+        const T* a = reinterpret_cast<const T*>(P.a);
+        const T* b = reinterpret_cast<const T*>(P.b);
+        const T* cc = reinterpret_cast<const T*>(P.c);
+        for (long long r = r0 + rlane; r < r1; r += 16) {
+            const long long row = gbase + r;
+            Chunk<T> va;
+            va.load(a + row * P.lda + c);
+            if (MODE == RED_STATS) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float v = va.get(e);
+                    s1[e] += v;
+                    s2[e] = fmaf(v, v, s2[e]);
+                }
+            } else if (MODE == RED_COLSUM) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s1[e] += va.get(e);
+            } else {
+                Chunk<T> vy, vx;
+                if (P.act) vy.load(b + row * P.ldb + c);
+                if (cc) vx.load(cc + row * P.ldc + c);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float gg = va.get(e);
+                    if (P.act) gg *= (vy.get(e) > 0.f ? 1.f : LRELU_SLOPE);
+                    s1[e] += gg;
+                    if (cc) s2[e] = fmaf(gg, (vx.get(e) - mu[e]) * rs[e], s2[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        float v = s1[e];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        s1[e] = v;
+        if (MODE != RED_COLSUM) {
+            float u = s2[e];
+            u += __shfl_xor(u, 16, 64);
+            u += __shfl_xor(u, 32, 64);
+            s2[e] = u;
+        }
+    }
+    if (c_ok && (threadIdx.x & 63) < 16) {
+        const long long o = (long long)g * P.C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (MODE == RED_COLSUM) {
+                atomicAdd(P.of + o + e, s1[e] * P.scale);
+            } else {
+                atomicAdd(P.o1 + o + e, (double)s1[e]);
+                if (P.o2) atomicAdd(P.o2 + o + e, (double)s2[e]);
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch_colreduce(int dtype, RedParams P, int groups, hipStream_t st, const char* who) {
+    const int vec = dtype_vec(dtype);
+    const int gx = (P.C / vec + 15) / 16;
+    long long want = 4096 / ((long long)gx * groups);
+    if (want < 1) want = 1;
+    long long rpb = (P.rows_per_group + want - 1) / want;
+    if (rpb < 128) rpb = 128;
+    if (rpb > 1 << 20) rpb = 1 << 20;
+    P.rows_per_block = (int)rpb;
+    const long long gy = (P.rows_per_group + rpb - 1) / rpb;
+    BG_CHECK_ARG(gy <= 65535 && groups <= 65535, "%s: grid too large", who);
+    dim3 grid(gx, (unsigned)gy, (unsigned)groups);
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, st, P));
+    BG_CHECK_LAUNCH(who);
+    return BG_OK;
+}
+
+// ------------------------------------------------------------- finalize ----
+__global__ void norm_finalize_kernel(const double* sum, const double* sumsq, long long rpg, int groups, int C,
+                                     const float* gamma, const float* beta, float eps, float momentum, float* rmean,
+                                     float* rvar, float* mean, float* rstd, float* scale, float* shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    const int c = i % C;
+    const double n = (double)rpg;
+    const double m = sum[i] / n;
+    double var = sumsq[i] / n - m * m;
+    if (var < 0.0 || rpg == 1) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    mean[i] = (float)m;
+    rstd[i] = r;
+    scale[i] = gm * r;
+    shift[i] = bt - (float)m * gm * r;
+    if (rmean && groups == 1) {
+        // nn.BatchNorm2d: running = (1-mom)*running + mom*batch, unbiased variance
+        const double unb = rpg > 1 ? var * n / (n - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void norm_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rmean,
+                                        const float* rvar, float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float r = 1.f / sqrtf(rvar[c] + eps);
+    const float gm = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    scale[c] = gm * r;
+    shift[c] = bt - rmean[c] * gm * r;
+}
+
+__global__ void norm_bwd_finalize_kernel(const double* s1, const double* s2, long long rpg, int groups, int C,
+                                         const float* gamma, const float* mean, const float* rstd, int train, float* A,
+                                         float* B, float* Cc, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float gm = gamma ? gamma[c] : 1.f;
+    double t1 = 0.0, t2 = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const long long i = (long long)g * C + c;
+        const double a1 = s1[i], a2 = s2 ? s2[i] : 0.0;
+        t1 += a1;
+        t2 += a2;
+        const double r = rstd[i], m = mean[i];
+        if (train) {
+            const double n = (double)rpg;
+            // dx = gm*r*( g - a1/n - xhat*a2/n ),  xhat = (x-m)*r
+            A[i] = (float)(gm * r);
+            B[i] = (float)(-gm * r * r * (a2 / n));
+            Cc[i] = (float)(-gm * r * (a1 / n) + gm * r * r * (a2 / n) * m);
+        } else {
+            A[i] = (float)(gm * r);
+            B[i] = 0.f;
+            Cc[i] = 0.f;
+        }
+    }
+    if (dgamma) dgamma[c] += (float)t2;
+    if (dbeta) dbeta[c] += (float)t1;
+}
+
+// ------------------------------------------------------------ element-wise --
+struct EwParams {
+    const void* x; int ldx;
+    const float* scale; const float* shift;
+    const void* res; int ldres;
+    void* y; int ldy;
+    long long rows; int C; long long rows_per_group; int act;
+};
+
+template <typename T>
+__global__ void norm_act_fwd_kernel(EwParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = P.C / VEC;
+    const long long total = P.rows * cv;
+    const T* x = reinterpret_cast<const T*>(P.x);
+    const T* res = reinterpret_cast<const T*>(P.res);
+    T* y = reinterpret_cast<T*>(P.y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        const long long row = i / cv;
+        Chunk<T> vx, vr, vo;
+        vx.load(x + row * P.ldx + c);
+        if (res) vr.load(res + row * P.ldres + c);
+        const long long so = (row / P.rows_per_group) * P.C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float z = vx.get(e);
+            if (P.scale) z = fmaf(z, P.scale[so + e], P.shift[so + e]);
+            if (res) z += vr.get(e);
+            if (P.act) z = lrelu_f(z);
+            vo.set(e, z);
+        }
+        vo.store(y + row * P.ldy + c);
+    }
+}
+
+struct EwBwdParams {
+    const void* dy; int lddy;
+    const void* y; int ldy;
+    const void* x; int ldx;
+    const float* A; const float* B; const float* Cc;
+    void* dx; int lddx;
+    void* dres; int lddres;
+    long long rows; int C; long long rows_per_group; int act;
+};
+
+template <typename T>
+__global__ void norm_act_bwd_apply_kernel(EwBwdParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = P.C / VEC;
+    const long long total = P.rows * cv;
+    const T* dy = reinterpret_cast<const T*>(P.dy);
+    const T* y = reinterpret_cast<const T*>(P.y);
+    const T* x = reinterpret_cast<const T*>(P.x);
+    T* dx = reinterpret_cast<T*>(P.dx);
+    T* dres = reinterpret_cast<T*>(P.dres);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        const long long row = i / cv;
+        Chunk<T> vg, vy, vx, vo;
+        vg.load(dy + row * P.lddy + c);
+        if (P.act) vy.load(y + row * P.ldy + c);
+        if (P.A && P.B) vx.load(x + row * P.ldx + c);
+        const long long so = (row / P.rows_per_group) * P.C + c;
+        float g[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            g[e] = vg.get(e);
+            if (P.act) g[e] *= (vy.get(e) > 0.f ? 1.f : LRELU_SLOPE);
+        }
+        if (dres) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) vo.set(e, g[e]);
+            vo.store(dres + row * P.lddres + c);
+        }
+        if (dx) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float d = g[e];
+                if (P.A) {
+                    d *= P.A[so + e];
+                    if (P.B) d += fmaf(P.B[so + e], vx.get(e), P.Cc[so + e]);
+                }
+                vo.set(e, d);
+            }
+            vo.store(dx + row * P.lddx + c);
+        }
+    }
+}
+
+inline unsigned ew_grid(long long total) {
+    long long g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int check_rows(int dtype, long long rows, int C, int groups, const char* who) {
+    BG_CHECK_ARG(dtype_ok(dtype), "%s: bad dtype", who);
+    BG_CHECK_ARG(rows > 0 && C > 0 && groups > 0 && rows % groups == 0, "%s: rows=%lld C=%d groups=%d", who, rows, C,
+                 groups);
+    BG_CHECK_ARG(C % dtype_vec(dtype) == 0, "%s: C=%d must be a multiple of %d", who, C, dtype_vec(dtype));
+    return BG_OK;
+}
+#define CHECK_LD(ld, who) \
+    BG_CHECK_ARG((ld) >= C && (ld) % dtype_vec(dtype) == 0, "%s: bad pixel stride %d for C=%d", who, (int)(ld), C)
+
+}  // namespace
+
+extern "C" int bg_norm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, int32_t groups,
+                             double* sum, double* sumsq, void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_norm_stats");
+    if (rc) return rc;
+    CHECK_LD(ldx, "bg_norm_stats");
+    BG_CHECK_ARG(x && sum && sumsq && aligned16(x), "bg_norm_stats: null/unaligned pointer");
+    RedParams P{};
+    P.a = x; P.lda = ldx; P.C = C; P.rows_per_group = rows / groups; P.o1 = sum; P.o2 = sumsq;
+    return launch_colreduce<RED_STATS>(dtype, P, groups, (hipStream_t)stream, "bg_norm_stats");
+}
+
+extern "C" int bg_colsum(int32_t dtype, const void* x, int32_t ldx, int64_t rows, int32_t C, int32_t groups,
+                         float scale, float* out, void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_colsum");
+    if (rc) return rc;
+    CHECK_LD(ldx, "bg_colsum");
+    BG_CHECK_ARG(x && out && aligned16(x), "bg_colsum: null/unaligned pointer");
+    RedParams P{};
+    P.a = x; P.lda = ldx; P.C = C; P.rows_per_group = rows / groups; P.of = out; P.scale = scale;
+    return launch_colreduce<RED_COLSUM>(dtype, P, groups, (hipStream_t)stream, "bg_colsum");
+}
+
+extern "C" int bg_norm_act_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
+                                      const void* x, int32_t ldx, const float* mean, const float* rstd, int64_t rows,
+                                      int32_t C, int32_t groups, int32_t act, double* s1, double* s2, void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_reduce");
+    if (rc) return rc;
+    CHECK_LD(lddy, "bg_norm_act_bwd_reduce");
+    BG_CHECK_ARG(dy && s1 && aligned16(dy), "bg_norm_act_bwd_reduce: null/unaligned pointer");
+    if (act) {
+        BG_CHECK_ARG(y && aligned16(y), "bg_norm_act_bwd_reduce: act needs y");
+        CHECK_LD(ldy, "bg_norm_act_bwd_reduce");
+    }
+    if (x) {
+        BG_CHECK_ARG(aligned16(x) && s2 && mean && rstd, "bg_norm_act_bwd_reduce: x needs mean/rstd/s2");
+        CHECK_LD(ldx, "bg_norm_act_bwd_reduce");
+    }
+    RedParams P{};
+    P.a = dy; P.lda = lddy; P.b = y; P.ldb = ldy; P.c = x; P.ldc = ldx;
+    P.mean = mean; P.rstd = rstd; P.act = act; P.C = C; P.rows_per_group = rows / groups;
+    P.o1 = s1; P.o2 = x ? s2 : nullptr;
+    return launch_colreduce<RED_BWD>(dtype, P, groups, (hipStream_t)stream, "bg_norm_act_bwd_reduce");
+}
+
+extern "C" int bg_norm_finalize(const double* sum, const double* sumsq, int64_t rows_per_group, int32_t groups,
+                                int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                                float* shift, void* stream) {
+    BG_CHECK_ARG(sum && sumsq && mean && rstd && scale && shift && rows_per_group > 0 && groups > 0 && C > 0,
+                 "bg_norm_finalize: bad args");
+    BG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bg_norm_finalize: running stats must come in pairs");
+    BG_CHECK_ARG(!(running_mean && groups != 1), "bg_norm_finalize: running stats only with batch statistics");
+    const int n = groups * C;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq,
+                       (long long)rows_per_group, groups, C, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                       rstd, scale, shift);
+    BG_CHECK_LAUNCH("norm_finalize_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    BG_CHECK_ARG(C > 0 && running_mean && running_var && scale && shift, "bg_norm_eval_affine: bad args");
+    hipLaunchKernelGGL(norm_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    BG_CHECK_LAUNCH("norm_eval_affine_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_bwd_finalize(const double* s1, const double* s2, int64_t rows_per_group, int32_t groups,
+                                    int32_t C, const float* gamma, const float* mean, const float* rstd, int32_t train,
+                                    float* A, float* B, float* Cc, float* dgamma, float* dbeta, void* stream) {
+    BG_CHECK_ARG(s1 && mean && rstd && A && B && Cc && rows_per_group > 0 && groups > 0 && C > 0,
+                 "bg_norm_bwd_finalize: bad args");
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s1, s2,
+                       (long long)rows_per_group, groups, C, gamma, mean, rstd, train, A, B, Cc, dgamma, dbeta);
+    BG_CHECK_LAUNCH("norm_bwd_finalize_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
+                               const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C,
+                               int32_t groups, int32_t act, void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_fwd");
+    if (rc) return rc;
+    CHECK_LD(ldx, "bg_norm_act_fwd");
+    CHECK_LD(ldy, "bg_norm_act_fwd");
+    BG_CHECK_ARG(x && y && aligned16(x) && aligned16(y), "bg_norm_act_fwd: null/unaligned pointer");
+    BG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "bg_norm_act_fwd: scale/shift must come in pairs");
+    if (res) {
+        BG_CHECK_ARG(aligned16(res), "bg_norm_act_fwd: unaligned res");
+        CHECK_LD(ldres, "bg_norm_act_fwd");
+    }
+    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, rows, C, rows / groups, act};
+    const long long total = rows * (C / dtype_vec(dtype));
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, P));
+    BG_CHECK_LAUNCH("norm_act_fwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
+                                     const void* x, int32_t ldx, const float* A, const float* B, const float* Cc,
+                                     void* dx, int32_t lddx, void* dres, int32_t lddres, int64_t rows, int32_t C,
+                                     int32_t groups, int32_t act, void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_apply");
+    if (rc) return rc;
+    CHECK_LD(lddy, "bg_norm_act_bwd_apply");
+    BG_CHECK_ARG(dy && aligned16(dy) && (dx || dres), "bg_norm_act_bwd_apply: null/unaligned pointer");
+    if (act) {
+        BG_CHECK_ARG(y && aligned16(y), "bg_norm_act_bwd_apply: act needs y");
+        CHECK_LD(ldy, "bg_norm_act_bwd_apply");
+    }
+    BG_CHECK_ARG(!(B && !A) && ((B == nullptr) == (Cc == nullptr)), "bg_norm_act_bwd_apply: A/B/Cc inconsistent");
+    if (A && B) {
+        BG_CHECK_ARG(x && aligned16(x), "bg_norm_act_bwd_apply: B needs x");
+        CHECK_LD(ldx, "bg_norm_act_bwd_apply");
+    }
+    if (dx) {
+        BG_CHECK_ARG(aligned16(dx), "bg_norm_act_bwd_apply: unaligned dx");
+        CHECK_LD(lddx, "bg_norm_act_bwd_apply");
+    }
+    if (dres) {
+        BG_CHECK_ARG(aligned16(dres), "bg_norm_act_bwd_apply: unaligned dres");
+        CHECK_LD(lddres, "bg_norm_act_bwd_apply");
+    }
+    EwBwdParams P{dy, lddy, y, ldy, x, ldx, A, B, Cc, dx, lddx, dres, lddres, rows, C, rows / groups, act};
+    const long long total = rows * (C / dtype_vec(dtype));
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, P));
+    BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel");
+    return BG_OK;
+}

@@ -1,0 +1,324 @@
+// Bilinear resize (align_corners=True), row broadcast, dtype/layout conversion.
+// HBM-bound element-wise kernels: lanes along channels, 16 bytes per lane.
+#include "common.h"
+
+namespace {
+
+// PyTorch's align_corners=True source index, evaluated in fp32 exactly as
+// aten's area_pixel_compute_source_index does for float inputs.
+__device__ __forceinline__ void src_index(int o, float ratio, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    const float r = ratio * (float)o;
+    i0 = (int)r;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = r - (float)i0;
+    l0 = 1.f - l1;
+}
+__host__ __device__ inline float ac_ratio(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+struct RsParams {
+    const void* x; int ldx;
+    void* y; int ldy;
+    int N, Hi, Wi, Ho, Wo, C;
+    float rh, rw;
+};
+
+template <typename TI, typename TO>
+__global__ void resize_fwd_kernel(RsParams P) {
+    constexpr int V = 4;  // 4 channels per thread (16 B of f32 / 8 B of bf16): works for both dtypes
+    const int cv = P.C / V;
+    const long long total = (long long)P.N * P.Ho * P.Wo * cv;
+    const TI* x = reinterpret_cast<const TI*>(P.x);
+    TO* y = reinterpret_cast<TO*>(P.y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        long long t = i / cv;
+        const int wo = (int)(t % P.Wo);
+        t /= P.Wo;
+        const int ho = (int)(t % P.Ho);
+        const int n = (int)(t / P.Ho);
+        int h0, h1, w0, w1;
+        float lh0, lh1, lw0, lw1;
+        src_index(ho, P.rh, P.Hi, h0, h1, lh0, lh1);
+        src_index(wo, P.rw, P.Wi, w0, w1, lw0, lw1);
+        const TI* b = x + (long long)n * P.Hi * P.Wi * P.ldx + c;
+        const TI* p00 = b + ((long long)h0 * P.Wi + w0) * P.ldx;
+        const TI* p01 = b + ((long long)h0 * P.Wi + w1) * P.ldx;
+        const TI* p10 = b + ((long long)h1 * P.Wi + w0) * P.ldx;
+        const TI* p11 = b + ((long long)h1 * P.Wi + w1) * P.ldx;
+        TO* o = y + (((long long)n * P.Ho + ho) * P.Wo + wo) * P.ldy + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float v = lh0 * (lw0 * Elem<TI>::to_f(p00[e]) + lw1 * Elem<TI>::to_f(p01[e])) +
+                            lh1 * (lw0 * Elem<TI>::to_f(p10[e]) + lw1 * Elem<TI>::to_f(p11[e]));
+            o[e] = Elem<TO>::from_f(v);
+        }
+    }
+}
+
+// Adjoint as a gather: every source pixel collects from the output pixels whose
+// forward stencil touches it, using the SAME fp32 index arithmetic as forward.
+template <typename TG, typename TX>
+__global__ void resize_bwd_kernel(RsParams P /* x = dy [Ho,Wo], y = dx [Hi,Wi] */) {
+    constexpr int V = 4;
+    const int cv = P.C / V;
+    const long long total = (long long)P.N * P.Hi * P.Wi * cv;
+    const TG* dy = reinterpret_cast<const TG*>(P.x);
+    TX* dx = reinterpret_cast<TX*>(P.y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        long long t = i / cv;
+        const int wi = (int)(t % P.Wi);
+        t /= P.Wi;
+        const int hi = (int)(t % P.Hi);
+        const int n = (int)(t / P.Hi);
+        // candidate output rows: those whose source coordinate lies in (hi-1, hi+1)
+        int ho_lo = 0, ho_hi = P.Ho - 1, wo_lo = 0, wo_hi = P.Wo - 1;
+        if (P.rh > 0.f) {
+            ho_lo = (int)floorf((float)(hi - 1) / P.rh) - 1;
+            ho_hi = (int)ceilf((float)(hi + 1) / P.rh) + 1;
+            if (ho_lo < 0) ho_lo = 0;
+            if (ho_hi > P.Ho - 1) ho_hi = P.Ho - 1;
+        }
+        if (P.rw > 0.f) {
+            wo_lo = (int)floorf((float)(wi - 1) / P.rw) - 1;
+            wo_hi = (int)ceilf((float)(wi + 1) / P.rw) + 1;
+            if (wo_lo < 0) wo_lo = 0;
+            if (wo_hi > P.Wo - 1) wo_hi = P.Wo - 1;
+        }
+        float acc[V] = {0.f, 0.f, 0.f, 0.f};
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            int h0, h1;
+            float lh0, lh1;
+            src_index(ho, P.rh, P.Hi, h0, h1, lh0, lh1);
+            float wh = 0.f;
+            if (h0 == hi) wh += lh0;
+            if (h1 == hi) wh += lh1;
+            if (wh == 0.f) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                int w0, w1;
+                float lw0, lw1;
+                src_index(wo, P.rw, P.Wi, w0, w1, lw0, lw1);
+                float ww = 0.f;
+                if (w0 == wi) ww += lw0;
+                if (w1 == wi) ww += lw1;
+                if (ww == 0.f) continue;
+                const TG* g = dy + (((long long)n * P.Ho + ho) * P.Wo + wo) * P.ldx + c;
+                const float f = wh * ww;
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(f, Elem<TG>::to_f(g[e]), acc[e]);
+            }
+        }
+        TX* o = dx + (((long long)n * P.Hi + hi) * P.Wi + wi) * P.ldy + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = Elem<TX>::from_f(acc[e]);
+    }
+}
+
+template <typename T>
+__global__ void broadcast_rows_kernel(const float* v, float scale, T* y, int ldy, long long rows, int C,
+                                      long long rpg) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long total = rows * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        const long long row = i / cv;
+        const float* s = v + (row / rpg) * C + c;
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, s[e] * scale);
+        o.store(y + row * ldy + c);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void cast_rows_kernel(const TS* src, int lds, TD* dst, int ldd, long long rows, int C) {
+    constexpr int V = 4;
+    const int cv = C / V;
+    const long long total = rows * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const long long row = i / cv;
+        const TS* s = src + row * lds + c;
+        TD* d = dst + row * ldd + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = Elem<TD>::from_f(Elem<TS>::to_f(s[e]));
+    }
+}
+
+template <typename T>
+__global__ void axpy_rows_kernel(const T* x, int ldx, T* y, int ldy, long long rows, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long total = rows * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        const long long row = i / cv;
+        Chunk<T> a, b;
+        a.load(x + row * ldx + c);
+        b.load(y + row * ldy + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) b.set(e, a.get(e) + b.get(e));
+        b.store(y + row * ldy + c);
+    }
+}
+
+// NCHW fp32 -> NHWC T (zero-filled channel padding).  One thread per pixel:
+// reads are coalesced along pixels for every channel, writes are Cp*sizeof(T)
+// contiguous bytes per lane.  C is small on this path (the field channels).
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int N, int C, int HW, int Cp, int ldd) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW);
+        const int p = (int)(i - (long long)n * HW);
+        const float* s = src + (long long)n * C * HW + p;
+        T* d = dst + i * ldd;
+        for (int c = 0; c < C; ++c) d[c] = Elem<T>::from_f(s[(long long)c * HW]);
+        for (int c = C; c < Cp; ++c) d[c] = Elem<T>::from_f(0.f);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, int lds, float* dst, int N, int C, int HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW);
+        const int p = (int)(i - (long long)n * HW);
+        const T* s = src + i * lds;
+        float* d = dst + (long long)n * C * HW + p;
+        for (int c = 0; c < C; ++c) d[(long long)c * HW] = Elem<T>::to_f(s[c]);
+    }
+}
+
+__global__ void fill_kernel(float* p, float v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+inline unsigned ew_grid(long long total) {
+    long long g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int check_rs(int dt_a, int dt_b, const void* a, int lda, void* b, int ldb, int N, int Hi, int Wi, int Ho, int Wo,
+             int C, const char* who) {
+    BG_CHECK_ARG(dtype_ok(dt_a) && dtype_ok(dt_b), "%s: bad dtype", who);
+    BG_CHECK_ARG(a && b && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "%s: bad args", who);
+    BG_CHECK_ARG(C % 4 == 0 && lda >= C && ldb >= C && lda % 4 == 0 && ldb % 4 == 0, "%s: C/ld must be multiples of 4", who);
+    return BG_OK;
+}
+
+}  // namespace
+
+#define RS_DISPATCH(dta, dtb, KERNEL, ...)                                                            \
+    do {                                                                                              \
+        if ((dta) == BG_BF16 && (dtb) == BG_BF16) hipLaunchKernelGGL((KERNEL<bf16_t, bf16_t>), __VA_ARGS__); \
+        else if ((dta) == BG_BF16 && (dtb) == BG_F32) hipLaunchKernelGGL((KERNEL<bf16_t, float>), __VA_ARGS__); \
+        else if ((dta) == BG_F32 && (dtb) == BG_BF16) hipLaunchKernelGGL((KERNEL<float, bf16_t>), __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<float, float>), __VA_ARGS__);                                  \
+    } while (0)
+
+extern "C" int bg_resize_bilinear_fwd(int32_t in_dtype, int32_t out_dtype, const void* x, int32_t ldx, void* y,
+                                      int32_t ldy, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                      int32_t C, void* stream) {
+    int rc = check_rs(in_dtype, out_dtype, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, "bg_resize_bilinear_fwd");
+    if (rc) return rc;
+    RsParams P{x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, ac_ratio(Hi, Ho), ac_ratio(Wi, Wo)};
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    RS_DISPATCH(in_dtype, out_dtype, resize_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, P);
+    BG_CHECK_LAUNCH("resize_fwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_resize_bilinear_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int32_t lddy, void* dx,
+                                      int32_t lddx, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                      int32_t C, void* stream) {
+    int rc = check_rs(dy_dtype, dx_dtype, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, "bg_resize_bilinear_bwd");
+    if (rc) return rc;
+    RsParams P{dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, ac_ratio(Hi, Ho), ac_ratio(Wi, Wo)};
+    const long long total = (long long)N * Hi * Wi * (C / 4);
+    RS_DISPATCH(dy_dtype, dx_dtype, resize_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, P);
+    BG_CHECK_LAUNCH("resize_bwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_broadcast_rows(int32_t dtype, const float* v, float scale, void* y, int32_t ldy, int64_t rows,
+                                 int32_t C, int32_t groups, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && v && y && aligned16(y) && rows > 0 && groups > 0 && rows % groups == 0,
+                 "bg_broadcast_rows: bad args");
+    BG_CHECK_ARG(C % dtype_vec(dtype) == 0 && ldy >= C && ldy % dtype_vec(dtype) == 0, "bg_broadcast_rows: bad C/ld");
+    const long long total = rows * (C / dtype_vec(dtype));
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((broadcast_rows_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, v, scale, (T*)y, ldy, (long long)rows, C,
+                                                   (long long)(rows / groups)));
+    BG_CHECK_LAUNCH("broadcast_rows_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_cast_rows(int32_t src_dtype, int32_t dst_dtype, const void* src, int32_t lds, void* dst, int32_t ldd,
+                            int64_t rows, int32_t C, void* stream) {
+    BG_CHECK_ARG(dtype_ok(src_dtype) && dtype_ok(dst_dtype) && src && dst && rows > 0 && C > 0, "bg_cast_rows: bad args");
+    BG_CHECK_ARG(C % 4 == 0 && lds >= C && ldd >= C, "bg_cast_rows: C must be a multiple of 4, ld >= C");
+    const long long total = rows * (C / 4);
+#define CAST_ARGS(TS, TD) dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const TS*)src, lds, (TD*)dst, ldd, (long long)rows, C
+    if (src_dtype == BG_BF16 && dst_dtype == BG_BF16) hipLaunchKernelGGL((cast_rows_kernel<bf16_t, bf16_t>), CAST_ARGS(bf16_t, bf16_t));
+    else if (src_dtype == BG_BF16) hipLaunchKernelGGL((cast_rows_kernel<bf16_t, float>), CAST_ARGS(bf16_t, float));
+    else if (dst_dtype == BG_BF16) hipLaunchKernelGGL((cast_rows_kernel<float, bf16_t>), CAST_ARGS(float, bf16_t));
+    else hipLaunchKernelGGL((cast_rows_kernel<float, float>), CAST_ARGS(float, float));
+#undef CAST_ARGS
+    BG_CHECK_LAUNCH("cast_rows_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_axpy_rows(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t C,
+                            void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && x && y && aligned16(x) && aligned16(y) && rows > 0, "bg_axpy_rows: bad args");
+    BG_CHECK_ARG(C % dtype_vec(dtype) == 0 && ldx >= C && ldy >= C && ldx % dtype_vec(dtype) == 0 &&
+                     ldy % dtype_vec(dtype) == 0, "bg_axpy_rows: bad C/ld");
+    const long long total = rows * (C / dtype_vec(dtype));
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((axpy_rows_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, (long long)rows, C));
+    BG_CHECK_LAUNCH("axpy_rows_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_nchw_to_nhwc(int32_t dst_dtype, const float* src, void* dst, int32_t N, int32_t C, int32_t HW,
+                               int32_t Cp, int32_t ldd, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dst_dtype) && src && dst && N > 0 && C > 0 && HW > 0 && Cp >= C && ldd >= Cp,
+                 "bg_nchw_to_nhwc: bad args");
+    const long long total = (long long)N * HW;
+    BG_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                                       (hipStream_t)stream, src, (T*)dst, N, C, HW, Cp, ldd));
+    BG_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, float* dst, int32_t N, int32_t C,
+                               int32_t HW, void* stream) {
+    BG_CHECK_ARG(dtype_ok(src_dtype) && src && dst && N > 0 && C > 0 && HW > 0 && lds >= C, "bg_nhwc_to_nchw: bad args");
+    const long long total = (long long)N * HW;
+    BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+                                                       (hipStream_t)stream, (const T*)src, lds, dst, N, C, HW));
+    BG_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_fill_f32(float* p, float v, int64_t n, void* stream) {
+    BG_CHECK_ARG(p && n > 0, "bg_fill_f32: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, v, (long long)n);
+    BG_CHECK_LAUNCH("fill_kernel");
+    return BG_OK;
+}

@@ -1,0 +1,217 @@
+/*
+ * bgamd.h -- C ABI of libbgamd.so: the MI355X (gfx950) kernels behind the
+ * Bias-GAN conv-GAN training step.
+ *
+ * The reference has no C plugin ABI for this path: its arithmetic is torch.nn
+ * modules (src/deepCam/architecture/gpsro/deeplab.py, deeplab_gan.py,
+ * utils/losses.py) and its own pattern for a native op is a
+ * torch.autograd.Function around an extension's forward()/backward()
+ * (deeplab.py:9-22, Conv2dLocalFunction).  Each entry point below replaces the
+ * torch.nn op sequence named in its comment; the Python host mirror
+ * (bias-gan_amd/ops.py) binds them with ctypes from autograd.Function wrappers
+ * of exactly that shape.  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All pointers are DEVICE
+ *     pointers unless a comment says host.  The caller owns every buffer; the
+ *     library keeps no pointer after a call returns and has no global state.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as
+ *     void*); it never synchronises, allocates or frees.
+ *   - return value: 0 on success, a negative BG_E_* code otherwise;
+ *     bg_last_error() returns a thread-local message for the last failure.
+ *   - activations are NHWC ("pixel-major"): element (n,h,w,c) of a tensor with
+ *     pixel stride ld lives at ((n*H+h)*W+w)*ld + c.  ld >= C lets an op read
+ *     or write a channel slice of a wider buffer (concat without a copy).
+ *     C and ld must be multiples of 8 (bf16) / 4 (f32): 16-byte vectors.
+ *   - dtype: BG_BF16 = activations/weights in bfloat16 with fp32 accumulation
+ *     (the performance path), BG_F32 = everything fp32 (the parity path).
+ *     Statistics, losses, gradients of parameters and optimiser state are
+ *     always fp32 (statistic sums fp64).
+ *   - conv weights: forward uses [Cout][KH][KW][Cin] ("KRSC"); bwd_data uses the
+ *     transposed copy [Cin][KH][KW][Cout] ("CRSK") made by bg_transpose_krsc.
+ *     Depthwise weights are [KH][KW][C].
+ */
+#ifndef BGAMD_H
+#define BGAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_BF16 0
+#define BG_F32 1
+
+#define BG_OK 0
+#define BG_E_ARG (-1)    /* bad argument / shape the kernels do not support */
+#define BG_E_LAUNCH (-2) /* hipLaunch failed (message carries hipGetErrorString) */
+
+#define BG_ABI_VERSION 1
+
+int bg_abi_version(void);
+const char* bg_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Dense convolution as implicit GEMM on MFMA (nn.Conv2d with groups=1:
+ * deeplab.py:178,182 entry convs; :58,81,95 pointwise/skip 1x1; :331 ASPP
+ * dilated 3x3; :363-369 decoder; :622,626,630 1x1).
+ * out = floor((in + 2*pad - dil*(k-1) - 1)/stride) + 1 must hold for (H,Ho),(W,Wo).
+ * ------------------------------------------------------------------------- */
+typedef struct bg_conv_desc {
+    int32_t dtype;            /* BG_BF16 | BG_F32 */
+    int32_t N, H, W, Cin;     /* input  [N,H,W,Cin],  pixel stride ldx */
+    int32_t Ho, Wo, Cout;     /* output [N,Ho,Wo,Cout], pixel stride ldy */
+    int32_t KH, KW;
+    int32_t stride, pad, dil; /* symmetric, same for H and W */
+    int32_t ldx, ldy;
+} bg_conv_desc;
+
+/* y = conv(x, w) (+ bias[Cout], fp32, may be NULL).  w: KRSC, dtype = d->dtype. */
+int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
+/* dx = conv_transpose(dy, w).  wt: CRSK copy of the weights.  Overwrites dx. */
+int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
+/* dw += x (*) dy, dw fp32 KRSC (accumulated with float atomics; caller zeroes it
+ * once per backward pass).  dbias (fp32 [Cout], may be NULL) += sum over pixels of dy. */
+int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* stream);
+
+/* KRSC -> CRSK for a batch of layers in one launch.  tbl (device, n entries of 5
+ * int64: src_off, dst_off, K, RS, C in elements) describes each layer inside the
+ * flat buffers src/dst (same dtype). */
+int bg_transpose_krsc(int32_t dtype, const void* src, void* dst, const int64_t* tbl, int32_t n_layers,
+                      int64_t max_elems, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Depthwise 3x3 of SeparableConv2d_same, with fixed_padding folded in
+ * (deeplab.py:66-87: pad = dil on every side for k=3).  Ho = ceil(H/stride).
+ * w: [3][3][C] dtype; dw: [3][3][C] fp32 accumulated.
+ * ------------------------------------------------------------------------- */
+typedef struct bg_dwconv_desc {
+    int32_t dtype;
+    int32_t N, H, W, C;
+    int32_t Ho, Wo;
+    int32_t stride, dil;
+    int32_t ldx, ldy;
+} bg_dwconv_desc;
+int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const void* w, void* y, void* stream);
+int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, const void* w, void* dx, void* stream);
+int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Normalisation (BatchNorm2d train/eval, InstanceNorm2d, Identity) fused with
+ * the residual add (Block: x += skip, deeplab.py:141) and LeakyReLU(0.2)
+ * (deeplab.py:100,180,334,365).
+ *
+ * Rows are pixels: R = N*H*W rows of C channels.  `groups` = 1 for batch
+ * statistics, N for instance statistics; rows_per_group = R / groups.
+ * ------------------------------------------------------------------------- */
+/* sum[g,c] += sum_x, sumsq[g,c] += sum_x^2 (fp64, caller zeroes). */
+int bg_norm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t ldx, int32_t groups, double* sum,
+                  double* sumsq, void* stream);
+/* From the sums: mean/rstd (saved for backward, fp32 [groups,C]), the affine
+ * (scale, shift) the apply kernel uses, and the BatchNorm running-stat update
+ * (momentum, unbiased variance; running_* may be NULL).  gamma/beta may be NULL
+ * (InstanceNorm defaults: no affine).  A group of ONE element normalises to
+ * exactly 0 (mean = x, var = 0), the arithmetic the reference's torch 1.8 had. */
+int bg_norm_finalize(const double* sum, const double* sumsq, int64_t rows_per_group, int32_t groups, int32_t C,
+                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics. */
+int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* y = act( x*scale[g,c] + shift[g,c] + res ), scale/shift NULL = identity, res
+ * NULL = none, act: 0 none, 1 LeakyReLU(0.2).  y may alias x or res. */
+int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
+                    const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
+                    int32_t act, void* stream);
+/* Backward pass 1: g = dy * act'(y);  s1[g,c] += sum g, s2[g,c] += sum g*xhat
+ * (fp64, caller zeroes) with xhat = (x-mean)*rstd. */
+int bg_norm_act_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
+                           int32_t ldx, const float* mean, const float* rstd, int64_t rows, int32_t C,
+                           int32_t groups, int32_t act, double* s1, double* s2, void* stream);
+/* Coefficients of pass 2 (dx = A*g + B*x + Cc) and dgamma += sum_g s2, dbeta += sum_g s1
+ * (dgamma/dbeta/gamma may be NULL).  train != 0: batch/instance statistics
+ * (full formula); train == 0: dx = scale*g. */
+int bg_norm_bwd_finalize(const double* s1, const double* s2, int64_t rows_per_group, int32_t groups, int32_t C,
+                         const float* gamma, const float* mean, const float* rstd, int32_t train, float* A, float* B,
+                         float* Cc, float* dgamma, float* dbeta, void* stream);
+/* Backward pass 2: g = dy*act'(y); dx = A*g + B*x + Cc (A NULL: dx = g; dx NULL:
+ * skipped); dres = g (NULL: skipped).  dx may alias dy. */
+int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
+                          int32_t ldx, const float* A, const float* B, const float* Cc, void* dx, int32_t lddx,
+                          void* dres, int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Resampling / pooling / layout (deeplab.py:375,379,663 bilinear
+ * align_corners=True; :621 AdaptiveAvgPool2d((1,1)); torch.cat by ld slices).
+ * ------------------------------------------------------------------------- */
+int bg_resize_bilinear_fwd(int32_t in_dtype, int32_t out_dtype, const void* x, int32_t ldx, void* y, int32_t ldy,
+                           int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+/* dx (overwritten) = adjoint of the above applied to dy. */
+int bg_resize_bilinear_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx,
+                           int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+/* out[g,c] (fp32, caller zeroes) += scale * sum over the group's rows of x. */
+int bg_colsum(int32_t dtype, const void* x, int32_t ldx, int64_t rows, int32_t C, int32_t groups, float scale,
+              float* out, void* stream);
+/* y[row,c] = scale * v[g(row),c]  (v fp32 [groups,C]). */
+int bg_broadcast_rows(int32_t dtype, const float* v, float scale, void* y, int32_t ldy, int64_t rows, int32_t C,
+                      int32_t groups, void* stream);
+/* Strided 2-D copy with dtype conversion: dst[row*ldd + c] = src[row*lds + c], c < C. */
+int bg_cast_rows(int32_t src_dtype, int32_t dst_dtype, const void* src, int32_t lds, void* dst, int32_t ldd,
+                 int64_t rows, int32_t C, void* stream);
+/* NCHW fp32 (contiguous) -> NHWC dtype with channels [C, Cp) zero-filled, and back
+ * (adjoint direction used for gradients: NHWC -> NCHW fp32, first C channels). */
+int bg_nchw_to_nhwc(int32_t dst_dtype, const float* src, void* dst, int32_t N, int32_t C, int32_t HW, int32_t Cp,
+                    int32_t ldd, void* stream);
+int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, float* dst, int32_t N, int32_t C, int32_t HW,
+                    void* stream);
+int bg_fill_f32(float* p, float v, int64_t n, void* stream);
+int bg_axpy_rows(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t C,
+                 void* stream); /* y += x */
+
+/* ---------------------------------------------------------------------------
+ * Discriminator head nn.Linear(2048*h*w, 1) on the NCHW-flattened feature map
+ * (deeplab_gan.py:21,32-35).  x: NHWC features [N,HW,C]; wlin: fp32 in the
+ * reference's layout [C*HW] (index c*HW + p), so checkpoints interchange.
+ * ------------------------------------------------------------------------- */
+int bg_linear_head_fwd(int32_t dtype, const void* x, int32_t ldx, const float* wlin, const float* blin, float* logits,
+                       int32_t N, int32_t HW, int32_t C, void* stream);
+/* dx = dlogits[n] * w ; dw += sum_n dlogits[n]*x ; db += sum_n dlogits[n] (dw/db may be NULL). */
+int bg_linear_head_bwd(int32_t dtype, const void* x, int32_t ldx, const float* wlin, const float* dlogits, void* dx,
+                       int32_t lddx, float* dw, float* db, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Losses (utils/losses.py:129-172, train_gan.py:142-152, deeplab_gan.py:112).
+ * Each writes the scalar loss to *loss (device fp32) and, where given, the
+ * gradient for upstream weight 1 (callers scale).
+ * ------------------------------------------------------------------------- */
+/* mean_n( max(x,0) - x*y + log1p(exp(-|x|)) ); dx[n] = (sigmoid(x)-y)/N. */
+int bg_bce_logits(const float* x, const float* y, int32_t n, float* loss, float* dx, void* stream);
+/* Generator output and targets are NCHW fp32 at the module boundary (as in the
+ * reference), so the pixel losses run on flat fp32 arrays.
+ * loss += inv_norm * sum(|p-t|*w)  (w NULL = 1; caller zeroes loss). */
+int bg_l1_loss_fwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm, float* loss,
+                   void* stream);
+/* dp = sign(p-t) * w * coef[0] * inv_norm   (coef: device scalar = upstream gradient). */
+int bg_l1_loss_bwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm, const float* coef,
+                   float* dp, void* stream);
+/* loss += inv_norm * sum over (n,pixel) of (||g[n,:,pixel]||_2 - 1)^2, g NCHW fp32 (caller zeroes loss). */
+int bg_gp_penalty(const float* g, int32_t N, int32_t C, int32_t HW, float inv_norm, float* loss, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimiser over a flat fp32 parameter arena (optim.Adam / AdamW,
+ * utils/parsing_helpers.py:8-12) with the low-precision weight copy fused in.
+ * g is multiplied by grad_scale first (1/world_size after a SUM all-reduce).
+ * ------------------------------------------------------------------------- */
+int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf16 copy or NULL */, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int32_t decoupled, float bias_corr1,
+                 float bias_corr2, float grad_scale, void* stream);
+int bg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGAMD_H */

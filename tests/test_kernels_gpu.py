@@ -1,0 +1,432 @@
+"""Every C-ABI entry point of libbgamd.so against a plain PyTorch fp32 CPU
+evaluation of the same op on the same (seeded) inputs.  Runs on the MI355X.
+
+Tolerances (stated per test): BG_F32 kernels <= 1e-4 of the output's max
+magnitude (different reduction order only); BG_BF16 kernels are fed inputs that
+are already bf16-representable, so the only differences are fp32 accumulation
+order and the final bf16 rounding of the output (2^-8 relative): 1e-2 of max.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import bias_gan_amd  # noqa: E402
+from bias_gan_amd import _lib as L  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 1e-2
+
+
+def rnd(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(shape, generator=g) * scale
+    return t.to(dtype).to(torch.float32)  # representable in `dtype`
+
+
+def up(c, dtype):
+    v = 8 if dtype == torch.bfloat16 else 4
+    return (c + v - 1) // v * v
+
+
+def to_nhwc(x, dtype, ld=None, coff=0):
+    """NCHW fp32 cpu -> NHWC `dtype` cuda buffer [N,H,W,ld]; returns (buffer, view of the C-slice)."""
+    n, c, h, w = x.shape
+    cp = up(c, dtype)
+    ld = ld or cp
+    buf = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    buf[..., coff:coff + c] = x.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    return buf, buf[..., coff:]
+
+
+def from_nhwc(view, c):
+    return view[..., :c].permute(0, 3, 1, 2).float().cpu()
+
+
+def krsc(w, dtype):
+    co, ci, kh, kw = w.shape
+    out = torch.zeros(up(co, dtype), kh, kw, up(ci, dtype), dtype=dtype, device=DEV)
+    out[:co, :, :, :ci] = w.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    return out
+
+
+def assert_close(got, ref, rel, what=""):
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rel})"
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, dil
+    (2, 9, 7, 24, 40, 1, 1, 0, 1),
+    (2, 24, 20, 728, 728, 1, 1, 0, 1),
+    (2, 20, 18, 16, 128, 3, 1, 1, 1),
+    (2, 21, 19, 8, 128, 3, 2, 1, 1),
+    (1, 13, 11, 64, 32, 3, 1, 6, 6),
+    (2, 11, 9, 128, 256, 1, 2, 0, 1),
+    (1, 16, 16, 304, 256, 3, 1, 1, 1),
+    (3, 5, 6, 2048, 256, 3, 1, 2, 2),
+    (2, 8, 8, 4, 4, 1, 1, 0, 1),
+]
+
+
+def conv_desc(dtype, n, h, w, cin, cout, k, s, p, d, ldx, ldy):
+    ho = (h + 2 * p - d * (k - 1) - 1) // s + 1
+    wo = (w + 2 * p - d * (k - 1) - 1) // s + 1
+    return L.ConvDesc(L.dt(dtype), n, h, w, up(cin, dtype), ho, wo, up(cout, dtype), k, k, s, p, d, ldx, ldy), ho, wo
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("sliced", [False, True])
+def test_conv2d_fwd_bwd(case, dtype, sliced):
+    n, h, w, cin, cout, k, s, p, d = case
+    x = rnd((n, cin, h, w), 1, dtype)
+    wt = rnd((cout, cin, k, k), 2, dtype, 1.0 / math.sqrt(cin * k * k))
+    bias = rnd((cout,), 3, torch.float32)
+    cinp, coutp = up(cin, dtype), up(cout, dtype)
+    ldx = cinp + (16 if sliced else 0)
+    ldy = coutp + (24 if sliced else 0)
+    xoff, yoff = (8 if sliced else 0), (16 if sliced else 0)
+    desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, k, s, p, d, ldx, ldy)
+    xb, xv = to_nhwc(x, dtype, ldx, xoff)
+    wk = krsc(wt, dtype)
+    bpad = torch.zeros(coutp, device=DEV)
+    bpad[:cout] = bias.to(DEV)
+    yb = torch.full((n, ho, wo, ldy), 7.0, dtype=dtype, device=DEV)
+    yv = yb[..., yoff:]
+    L.call("bg_conv2d_fwd", desc, xv.data_ptr(), wk.data_ptr(), bpad.data_ptr(), yv.data_ptr())
+    ref = F.conv2d(x, wt, bias, s, p, d)
+    assert_close(from_nhwc(yv, cout), ref, tol(dtype), "fwd")
+    if sliced:  # nothing outside the slice was touched
+        assert (yb[..., :yoff] == 7.0).all() and (yb[..., yoff + coutp:] == 7.0).all()
+    if coutp > cout:
+        assert (yv[..., cout:coutp] == 0).all()
+
+    # backward
+    go = rnd((n, cout, ho, wo), 4, dtype)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, s, p, d).backward(go)
+    gb, gv = to_nhwc(go, dtype, ldy, yoff)
+    # CRSK copy through the batched transpose entry point
+    wtt = torch.empty(cinp * k * k * coutp, dtype=dtype, device=DEV)
+    tbl = torch.tensor([[0, 0, coutp, k * k, cinp]], dtype=torch.int64, device=DEV)
+    L.call("bg_transpose_krsc", L.dt(dtype), wk.data_ptr(), wtt.data_ptr(), tbl.data_ptr(), 1, wk.numel())
+    assert torch.equal(wtt.view(cinp, k * k, coutp), wk.view(coutp, k * k, cinp).permute(2, 1, 0).contiguous())
+    dxb = torch.full((n, h, w, ldx), 5.0, dtype=dtype, device=DEV)
+    dxv = dxb[..., xoff:]
+    L.call("bg_conv2d_bwd_data", desc, gv.data_ptr(), wtt.data_ptr(), dxv.data_ptr())
+    assert_close(from_nhwc(dxv, cin), xr.grad, tol(dtype), "bwd_data")
+    dw = torch.zeros(coutp, k, k, cinp, device=DEV)
+    db = torch.zeros(coutp, device=DEV)
+    L.call("bg_conv2d_bwd_weight", desc, xv.data_ptr(), gv.data_ptr(), dw.data_ptr(), db.data_ptr())
+    got_dw = dw[:cout, :, :, :cin].permute(0, 3, 1, 2).cpu()
+    assert_close(got_dw, wr.grad, 1e-4 if dtype == torch.float32 else 2e-3, "bwd_weight")
+    assert_close(db[:cout].cpu(), go.sum((0, 2, 3)), 1e-4 if dtype == torch.float32 else 2e-3, "dbias")
+    # accumulation semantics: a second call adds
+    L.call("bg_conv2d_bwd_weight", desc, xv.data_ptr(), gv.data_ptr(), dw.data_ptr(), None)
+    assert_close(dw[:cout, :, :, :cin].permute(0, 3, 1, 2).cpu(), 2 * wr.grad, 2e-3, "bwd_weight accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_mfma_layout_asymmetric(dtype):
+    """A = identity-like weights with an asymmetric input: catches a swapped
+    row/column map of the MFMA accumulator (cdna guide section 3)."""
+    n, h, w, c = 1, 16, 16, 128
+    x = torch.arange(n * c * h * w, dtype=torch.float32).reshape(n, c, h, w) % 251
+    wt = torch.zeros(c, c, 1, 1)
+    for i in range(c):
+        wt[i, (i * 7 + 3) % c, 0, 0] = 1.0  # permutation, not symmetric
+    desc, ho, wo = conv_desc(dtype, n, h, w, c, c, 1, 1, 0, 1, c, c)
+    xb, xv = to_nhwc(x, dtype)
+    yb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    L.call("bg_conv2d_fwd", desc, xv.data_ptr(), krsc(wt, dtype).data_ptr(), None, yb.data_ptr())
+    assert torch.equal(from_nhwc(yb, c), F.conv2d(x, wt))  # small integers: exact in bf16 too
+
+
+DW_CASES = [(2, 13, 18, 16, 1, 1), (2, 12, 10, 24, 2, 1), (1, 9, 7, 728, 1, 1), (2, 9, 7, 40, 1, 2), (1, 7, 5, 8, 2, 1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv(case, dtype):
+    n, h, w, c, s, d = case
+    x = rnd((n, c, h, w), 5, dtype)
+    wt = rnd((c, 1, 3, 3), 6, dtype, 0.3)
+    ho, wo = -(-h // s), -(-w // s)
+    ld = up(c, dtype) + 8
+    xb, xv = to_nhwc(x, dtype, ld, 8)
+    wk = torch.zeros(3, 3, up(c, dtype), dtype=dtype, device=DEV)
+    wk[:, :, :c] = wt[:, 0].permute(1, 2, 0).to(dtype).to(DEV)
+    desc = L.DwDesc(L.dt(dtype), n, h, w, up(c, dtype), ho, wo, s, d, ld, ld)
+    yb = torch.zeros(n, ho, wo, ld, dtype=dtype, device=DEV)
+    yv = yb[..., 8:]
+    L.call("bg_dwconv3x3_fwd", desc, xv.data_ptr(), wk.data_ptr(), yv.data_ptr())
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, (d, d, d, d)), wr, None, s, 0, d, groups=c)  # fixed_padding for k=3: (d, d)
+    assert ref.shape[2:] == (ho, wo)
+    assert_close(from_nhwc(yv, c), ref.detach(), tol(dtype), "dw fwd")
+    go = rnd(tuple(ref.shape), 7, dtype)
+    ref.backward(go)
+    gb, gv = to_nhwc(go, dtype, ld, 8)
+    dxb = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_bwd_data", desc, gv.data_ptr(), wk.data_ptr(), dxb[..., 8:].data_ptr())
+    assert_close(from_nhwc(dxb[..., 8:], c), xr.grad, tol(dtype), "dw bwd_data")
+    dw = torch.zeros(3, 3, up(c, dtype), device=DEV)
+    L.call("bg_dwconv3x3_bwd_weight", desc, xv.data_ptr(), gv.data_ptr(), dw.data_ptr())
+    assert_close(dw[:, :, :c].permute(2, 0, 1).cpu(), wr.grad[:, 0], 1e-4 if dtype == torch.float32 else 2e-3, "dw wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["batch", "instance", "eval", "identity"])
+@pytest.mark.parametrize("act,with_res", [(1, False), (0, True), (1, True)])
+def test_norm_act(dtype, mode, act, with_res):
+    n, h, w, c = 3, 7, 9, 24
+    x = rnd((n, c, h, w), 8, dtype, 2.0) + 0.5
+    res = rnd((n, c, h, w), 9, dtype)
+    gamma = torch.rand(c, generator=torch.Generator().manual_seed(1)) + 0.5
+    beta = torch.randn(c, generator=torch.Generator().manual_seed(2)) * 0.2
+    rmean0 = torch.randn(c, generator=torch.Generator().manual_seed(3)) * 0.1
+    rvar0 = torch.rand(c, generator=torch.Generator().manual_seed(4)) + 0.5
+    rows, groups = n * h * w, (n if mode == "instance" else 1)
+    xb, xv = to_nhwc(x, dtype)
+    rb, rv = to_nhwc(res, dtype)
+    yb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    dtc = L.dt(dtype)
+    f32 = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    f64 = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.float64)  # noqa: E731
+    g_d, b_d = gamma.to(DEV), beta.to(DEV)
+    rm_d, rv_d = rmean0.to(DEV), rvar0.to(DEV)
+    mean, rstd, scale, shift = f32(groups, c), f32(groups, c), f32(groups, c), f32(groups, c)
+    # ---- reference
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rmean0.clone(), rvar0.clone()
+    if mode == "batch":
+        z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    elif mode == "eval":
+        z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, False, 0.1, 1e-5)
+    elif mode == "instance":
+        z = F.instance_norm(xr, eps=1e-5)
+    else:
+        z = xr
+    if with_res:
+        z = z + rr
+    yref = F.leaky_relu(z, 0.2) if act else z
+    # ---- kernels
+    if mode in ("batch", "instance"):
+        s, ss = f64(groups, c), f64(groups, c)
+        L.call("bg_norm_stats", dtc, xv.data_ptr(), rows, c, c, groups, s.data_ptr(), ss.data_ptr())
+        aff = mode == "batch"
+        L.call("bg_norm_finalize", s.data_ptr(), ss.data_ptr(), rows // groups, groups, c,
+               g_d.data_ptr() if aff else None, b_d.data_ptr() if aff else None, 1e-5, 0.1,
+               rm_d.data_ptr() if aff else None, rv_d.data_ptr() if aff else None, mean.data_ptr(), rstd.data_ptr(),
+               scale.data_ptr(), shift.data_ptr())
+    elif mode == "eval":
+        L.call("bg_norm_eval_affine", c, g_d.data_ptr(), b_d.data_ptr(), rm_d.data_ptr(), rv_d.data_ptr(), 1e-5,
+               scale.data_ptr(), shift.data_ptr())
+        mean.copy_(rm_d), rstd.copy_(1.0 / torch.sqrt(rv_d + 1e-5))
+    ident = mode == "identity"
+    L.call("bg_norm_act_fwd", dtc, xv.data_ptr(), c, None if ident else scale.data_ptr(),
+           None if ident else shift.data_ptr(), rv.data_ptr() if with_res else None, c, yb.data_ptr(), c, rows, c, groups,
+           act)
+    assert_close(from_nhwc(yb, c), yref.detach(), tol(dtype), "fwd")
+    if mode == "batch":
+        assert_close(rm_d.cpu(), rm_ref, 1e-5, "running_mean")
+        assert_close(rv_d.cpu(), rv_ref, 1e-5, "running_var")
+    # ---- backward
+    go = rnd(tuple(yref.shape), 10, dtype)
+    yref.backward(go)
+    gb, gv = to_nhwc(go, dtype)
+    # the saved output the kernels see is the (possibly bf16-rounded) kernel output
+    A, B, Cc = f32(groups, c), f32(groups, c), f32(groups, c)
+    dgamma, dbeta = f32(c), f32(c)
+    dxb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    dresb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    if ident:
+        L.call("bg_norm_act_bwd_apply", dtc, gv.data_ptr(), c, yb.data_ptr(), c, None, 0, None, None, None,
+               dxb.data_ptr(), c, dresb.data_ptr() if with_res else None, c, rows, c, groups, act)
+    else:
+        s1, s2 = f64(groups, c), f64(groups, c)
+        L.call("bg_norm_act_bwd_reduce", dtc, gv.data_ptr(), c, yb.data_ptr(), c, xv.data_ptr(), c, mean.data_ptr(),
+               rstd.data_ptr(), rows, c, groups, act, s1.data_ptr(), s2.data_ptr())
+        aff = mode in ("batch", "eval")
+        L.call("bg_norm_bwd_finalize", s1.data_ptr(), s2.data_ptr(), rows // groups, groups, c,
+               g_d.data_ptr() if aff else None, mean.data_ptr(), rstd.data_ptr(), 0 if mode == "eval" else 1,
+               A.data_ptr(), B.data_ptr(), Cc.data_ptr(), dgamma.data_ptr() if aff else None,
+               dbeta.data_ptr() if aff else None)
+        L.call("bg_norm_act_bwd_apply", dtc, gv.data_ptr(), c, yb.data_ptr(), c, xv.data_ptr(), c, A.data_ptr(),
+               B.data_ptr(), Cc.data_ptr(), dxb.data_ptr(), c, dresb.data_ptr() if with_res else None, c, rows, c, groups,
+               act)
+        if aff:
+            assert_close(dgamma.cpu(), gr.grad, 5e-4 if dtype == torch.float32 else 2e-2, "dgamma")
+            assert_close(dbeta.cpu(), br.grad, 5e-4 if dtype == torch.float32 else 2e-2, "dbeta")
+    assert_close(from_nhwc(dxb, c), xr.grad, 5e-4 if dtype == torch.float32 else 2e-2, "dx")
+    if with_res:
+        assert_close(from_nhwc(dresb, c), rr.grad, tol(dtype), "dres")
+
+
+def test_norm_single_element_instance():
+    """InstanceNorm on a 1x1 map (global-pool branch): mean = x, var = 0 -> output 0."""
+    n, c = 2, 16
+    x = torch.randn(n, 1, 1, c, device=DEV)
+    s = torch.zeros(n, c, device=DEV, dtype=torch.float64)
+    ss = torch.zeros_like(s)
+    L.call("bg_norm_stats", L.F32, x.data_ptr(), n, c, c, n, s.data_ptr(), ss.data_ptr())
+    mean, rstd, scale, shift = (torch.zeros(n, c, device=DEV) for _ in range(4))
+    L.call("bg_norm_finalize", s.data_ptr(), ss.data_ptr(), 1, n, c, None, None, 1e-5, 0.1, None, None, mean.data_ptr(),
+           rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    y = torch.empty_like(x)
+    L.call("bg_norm_act_fwd", L.F32, x.data_ptr(), c, scale.data_ptr(), shift.data_ptr(), None, 0, y.data_ptr(), c, n, c,
+           n, 1)
+    assert y.abs().max().item() < 1e-3 * x.abs().max().item()
+
+
+RESIZE_CASES = [(2, 5, 4, 17, 13, 8), (1, 1, 1, 6, 5, 16), (2, 6, 7, 6, 7, 4), (1, 9, 12, 33, 47, 12), (2, 8, 8, 3, 5, 4)]
+
+
+@pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                    (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("case", RESIZE_CASES)
+def test_resize_bilinear(case, dtypes):
+    n, hi, wi, ho, wo, c = case
+    din, dout = dtypes
+    x = rnd((n, c, hi, wi), 11, din)
+    xb = x.permute(0, 2, 3, 1).contiguous().to(din).to(DEV)
+    yb = torch.zeros(n, ho, wo, c, dtype=dout, device=DEV)
+    L.call("bg_resize_bilinear_fwd", L.dt(din), L.dt(dout), xb.data_ptr(), c, yb.data_ptr(), c, n, hi, wi, ho, wo, c)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=True)
+    assert_close(from_nhwc(yb, c), ref.detach(), 1e-5 if dout == torch.float32 else 1e-2, "resize fwd")
+    go = rnd((n, c, ho, wo), 12, dout)
+    ref.backward(go)
+    gb = go.permute(0, 2, 3, 1).contiguous().to(dout).to(DEV)
+    dxb = torch.zeros(n, hi, wi, c, dtype=din, device=DEV)
+    L.call("bg_resize_bilinear_bwd", L.dt(dout), L.dt(din), gb.data_ptr(), c, dxb.data_ptr(), c, n, hi, wi, ho, wo, c)
+    assert_close(from_nhwc(dxb, c), xr.grad, 1e-5 if din == torch.float32 else 1e-2, "resize bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum_broadcast_cast_layout(dtype):
+    n, h, w, c = 3, 6, 5, 24
+    x = rnd((n, c, h, w), 13, dtype)
+    xb, xv = to_nhwc(x, dtype)
+    out = torch.zeros(n, c, device=DEV)
+    L.call("bg_colsum", L.dt(dtype), xv.data_ptr(), c, n * h * w, c, n, 1.0 / (h * w), out.data_ptr())
+    assert_close(out.cpu(), x.mean((2, 3)), 1e-5, "colsum")
+    yb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    L.call("bg_broadcast_rows", L.dt(dtype), out.data_ptr(), 2.0, yb.data_ptr(), c, n * h * w, c, n)
+    assert_close(from_nhwc(yb, c), (2.0 * x.mean((2, 3)))[:, :, None, None].expand(n, c, h, w), tol(dtype), "broadcast")
+    # cast with strides
+    dst = torch.zeros(n * h * w, c + 8, device=DEV)
+    L.call("bg_cast_rows", L.dt(dtype), L.F32, xv.data_ptr(), c, dst.data_ptr(), c + 8, n * h * w, c)
+    assert torch.equal(dst[:, :c].cpu(), x.permute(0, 2, 3, 1).reshape(-1, c))
+    # layout
+    xs = rnd((n, 5, h, w), 14, torch.float32).to(DEV)
+    nh = torch.full((n, h, w, 8), 3.0, dtype=dtype, device=DEV)
+    L.call("bg_nchw_to_nhwc", L.dt(dtype), xs.data_ptr(), nh.data_ptr(), n, 5, h * w, 8, 8)
+    assert_close(nh[..., :5].permute(0, 3, 1, 2).float().cpu(), xs.cpu(), tol(dtype), "nchw->nhwc")
+    assert (nh[..., 5:] == 0).all()
+    back = torch.zeros(n, 5, h, w, device=DEV)
+    L.call("bg_nhwc_to_nchw", L.dt(dtype), nh.data_ptr(), 8, back.data_ptr(), n, 5, h * w)
+    assert torch.equal(back.cpu(), nh[..., :5].permute(0, 3, 1, 2).float().cpu())
+    a = rnd((n * h * w, c), 15, dtype)
+    ab, bb = a.to(dtype).to(DEV), xv.reshape(-1, c).clone()
+    L.call("bg_axpy_rows", L.dt(dtype), ab.data_ptr(), c, bb.data_ptr(), c, n * h * w, c)
+    assert_close(bb.float().cpu(), a + x.permute(0, 2, 3, 1).reshape(-1, c), tol(dtype), "axpy")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_head(dtype):
+    n, h, w, c = 3, 4, 5, 64
+    x = rnd((n, c, h, w), 16, dtype)
+    wl = rnd((1, c * h * w), 17, torch.float32, 0.05)
+    bl = torch.tensor([0.3])
+    xb, xv = to_nhwc(x, dtype)
+    w_d, b_d = wl.to(DEV), bl.to(DEV)
+    logits = torch.zeros(n, 1, device=DEV)
+    L.call("bg_linear_head_fwd", L.dt(dtype), xv.data_ptr(), c, w_d.data_ptr(), b_d.data_ptr(), logits.data_ptr(), n,
+           h * w, c)
+    xr, wr, br = x.clone().requires_grad_(True), wl.clone().requires_grad_(True), bl.clone().requires_grad_(True)
+    ref = F.linear(xr.reshape(n, -1), wr, br)
+    assert_close(logits.cpu(), ref.detach(), 1e-5, "head fwd")
+    dl = torch.tensor([[0.5], [-1.0], [0.25]])
+    ref.backward(dl)
+    dxb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    dw, db = torch.zeros(1, c * h * w, device=DEV), torch.zeros(1, device=DEV)
+    L.call("bg_linear_head_bwd", L.dt(dtype), xv.data_ptr(), c, w_d.data_ptr(), dl.to(DEV).data_ptr(), dxb.data_ptr(), c,
+           dw.data_ptr(), db.data_ptr(), n, h * w, c)
+    assert_close(from_nhwc(dxb, c), xr.grad, tol(dtype), "head dx")
+    assert_close(dw.cpu(), wr.grad, 1e-5, "head dw")
+    assert_close(db.cpu(), br.grad, 1e-6, "head db")
+
+
+def test_losses():
+    n = 5
+    x = torch.randn(n, 1) * 3
+    y = torch.rand(n, 1)
+    loss, dx = torch.zeros(1, device=DEV), torch.zeros(n, 1, device=DEV)
+    L.call("bg_bce_logits", x.to(DEV).data_ptr(), y.to(DEV).data_ptr(), n, loss.data_ptr(), dx.data_ptr())
+    xr = x.clone().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(xr, y)
+    ref.backward()
+    assert_close(loss.cpu(), ref.detach().reshape(1), 1e-6, "bce")
+    assert_close(dx.cpu(), xr.grad, 1e-6, "bce grad")
+    p, t, w = torch.randn(2, 3, 9, 7), torch.randn(2, 3, 9, 7), torch.rand(2, 3, 9, 7)
+    p[0, 0, 0, 0] = t[0, 0, 0, 0]  # sign(0) = 0
+    for wt in (None, w):
+        l1 = torch.zeros(1, device=DEV)
+        pd, td = p.to(DEV), t.to(DEV)
+        wd = None if wt is None else wt.to(DEV)
+        L.call("bg_l1_loss_fwd", pd.data_ptr(), td.data_ptr(), L.ptr(wd), p.numel(), 1.0 / p.numel(), l1.data_ptr())
+        pr = p.clone().requires_grad_(True)
+        ref = ((pr - t).abs() * (1 if wt is None else wt)).mean()
+        ref.backward()
+        assert_close(l1.cpu(), ref.detach().reshape(1), 1e-5, "l1")
+        dp = torch.zeros_like(pd)
+        coef = torch.tensor([1.0], device=DEV)
+        L.call("bg_l1_loss_bwd", pd.data_ptr(), td.data_ptr(), L.ptr(wd), p.numel(), 1.0 / p.numel(), coef.data_ptr(),
+               dp.data_ptr())
+        assert_close(dp.cpu(), pr.grad, 1e-6, "l1 grad")
+    g = torch.randn(2, 6, 5, 4)
+    gp = torch.zeros(1, device=DEV)
+    L.call("bg_gp_penalty", g.to(DEV).data_ptr(), 2, 6, 20, 1.0 / 40, gp.data_ptr())
+    assert_close(gp.cpu(), ((g.norm(2, dim=1) - 1) ** 2).mean().reshape(1), 1e-5, "gp")
+
+
+def test_adam_matches_torch():
+    n = 1000
+    p0, g1, g2 = torch.randn(n), torch.randn(n) * 1e-3, torch.randn(n) * 1e-3
+    for decoupled in (0, 1):
+        pr = p0.clone().requires_grad_(True)
+        opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([pr], lr=1e-3, eps=1e-8, weight_decay=1e-2)
+        p, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        plp = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        for t, g in enumerate((g1, g2), 1):
+            pr.grad = g.clone()
+            opt.step()
+            L.call("bg_adam_step", p.data_ptr(), (2 * g).to(DEV).data_ptr(), m.data_ptr(), v.data_ptr(), plp.data_ptr(), n,
+                   1e-3, 0.9, 0.999, 1e-8, 1e-2, decoupled, 1 - 0.9 ** t, 1 - 0.999 ** t, 0.5)
+        assert_close(p.cpu(), pr.detach(), 1e-6, "adam")
+        assert torch.equal(plp.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def test_bad_arguments_raise():
+    d = L.ConvDesc(L.BF16, 1, 8, 8, 12, 8, 8, 16, 1, 1, 1, 0, 1, 12, 16)  # Cin not a multiple of 8
+    z = torch.zeros(8, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        L.call("bg_conv2d_fwd", d, z.data_ptr(), z.data_ptr(), None, z.data_ptr())
+    d = L.ConvDesc(L.BF16, 1, 8, 8, 16, 9, 8, 16, 1, 1, 1, 0, 1, 16, 16)  # wrong Ho
+    with pytest.raises(RuntimeError, match="conv arithmetic"):
+        L.call("bg_conv2d_fwd", d, z.data_ptr(), z.data_ptr(), None, z.data_ptr())
