@@ -1,0 +1,181 @@
+"""`comm` helper class with the reference's API (comm/distributed.py:10-204) for
+one process per GPU over RCCL (torch.distributed backend "nccl" on ROCm).
+
+Gradient synchronisation is NOT a per-parameter hook storm: a network's
+gradients live in one flat fp32 arena (runtime.Arena), so data parallelism is a
+handful of large all-reduces over that buffer on a side HIP stream
+(FlatAllReduce), launched when the backward pass ends and waited for only
+when the fused Adam needs the result -- the next forward pass runs meanwhile.
+xGMI is point-to-point (7 links/GPU), so few large messages beat many small ones.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class FlatAllReduce:
+    """SUM all-reduce of one flat tensor in `bucket_elems`-sized pieces on a side
+    stream.  Works on CPU tensors too (gloo), where it is simply asynchronous."""
+
+    def __init__(self, flat: torch.Tensor, group=None, bucket_elems: int = 32 * 1024 * 1024):
+        self.flat, self.group = flat, group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, int(bucket_elems))
+        self.cuda = flat.is_cuda
+        self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.works = []
+        self.launched = False
+
+    def buckets(self):
+        n = self.flat.numel()
+        return [(o, min(o + self.bucket_elems, n)) for o in range(0, n, self.bucket_elems)]
+
+    def launch(self):
+        """Start the reduction of the buffer's current contents (call after backward)."""
+        if self.launched or self.world_size == 1:
+            self.launched = True
+            return
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.stream):
+                for a, b in self.buckets():
+                    self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for a, b in self.buckets():
+                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched = True
+
+    def finish(self):
+        """Make the reduced values visible to the current stream (launches first if nobody did)."""
+        if not self.launched:
+            self.launch()
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.cuda and self.world_size > 1:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        self.launched = False
+
+
+class DistributedModel(nn.Module):
+    """Stand-in for apex.parallel.DistributedDataParallel (comm/distributed.py:195-199):
+    parameters broadcast from rank 0, gradients summed over ranks (the optimiser
+    divides by world size).  Keys gain the 'module.' prefix like DDP's."""
+
+    def __init__(self, module: nn.Module, group=None):
+        super().__init__()
+        self.module = module
+        self.group = group
+        self._ready = False
+
+    def _prepare(self):
+        arena = self.module.arena()
+        if not self._ready:
+            dist.broadcast(arena.master, src=0, group=self.group)
+            arena.weights_changed()
+            arena.sync()
+            arena.ddp = FlatAllReduce(arena.grad, self.group)
+            self._ready = True
+        return arena
+
+    def forward(self, *a, **kw):
+        self._prepare()
+        return self.module(*a, **kw)
+
+    def launch_grad_allreduce(self):
+        self._prepare().ddp.launch()
+
+
+class comm(object):
+
+    def __init__(self, mode="openmpi"):
+        port = "29500"
+        os.environ.setdefault("MASTER_PORT", port)
+        if "RANK" in os.environ and "WORLD_SIZE" in os.environ and mode != "dummy":
+            # launched by torch.distributed.run: one process per GPU, RCCL over xGMI
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if torch.cuda.is_available():
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+            if not dist.is_initialized():
+                dist.init_process_group(backend=backend)
+            return
+        if mode == "openmpi":
+            raise RuntimeError("the 'mpi' backend is not part of this build; launch with torch.distributed.run "
+                               "(RANK/WORLD_SIZE in the environment) or use mode='openmpi-nccl' / 'dummy'")
+        elif mode == "openmpi-nccl":
+            addrport = os.getenv("PMIX_SERVER_URI2").split("//")[1]
+            os.environ["MASTER_ADDR"] = addrport.split(":")[0]
+            comm_rank = int(os.getenv('OMPI_COMM_WORLD_RANK', 0))
+            comm_size = int(os.getenv("OMPI_COMM_WORLD_SIZE", 0))
+            dist.init_process_group(backend="nccl", rank=comm_rank, world_size=comm_size)
+        elif mode == "dummy":
+            os.environ.setdefault("MASTER_ADDR", "localhost")
+
+    def metric_average(self, val, name=None, op_name=None, device=None):
+        """SUM over ranks (times 1/size when op_name == 'average'), returned as a
+        Python float -- the reference's semantics, host sync included
+        (comm/distributed.py:12-34: the default op_name=None returns the SUM)."""
+        if dist.is_available() and dist.is_initialized():
+            fact = 1. / float(self.size()) if op_name == "average" else 1.
+            tensor = val.clone().detach().requires_grad_(False) if isinstance(val, torch.Tensor) else torch.tensor(val)
+            if device is not None:
+                tensor = tensor.to(device)
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+            return fact * tensor.item()
+        return val.item() if isinstance(val, torch.Tensor) else val
+
+    def printr(self, msg, rank=0):
+        if self.rank() == rank:
+            print(msg)
+
+    def size(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def rank(self):
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    def local_rank(self):
+        if dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+            return dist.get_rank() % torch.cuda.device_count()
+        return 0
+
+    def broadcast(self, tensor, root_rank, name=None):
+        if dist.is_available() and dist.is_initialized():
+            dist.broadcast(tensor, src=root_rank)
+        return tensor
+
+    @staticmethod
+    def _strip(sd):
+        return {k.replace("module.", ""): v for k, v in sd.items()}
+
+    def init_training_state(self, model, optimizer, checkpoint_name, device_id):
+        if (checkpoint_name is not None) and (os.path.isfile(checkpoint_name)):
+            checkpoint = torch.load(checkpoint_name, map_location=device_id)
+            optimizer.load_state_dict(checkpoint['optimizer'])
+            model.load_state_dict(self._strip(checkpoint['model']))
+            return checkpoint['step'], checkpoint['epoch']
+        return 0, 0
+
+    def init_gan_training_state(self, gmodel, dmodel, gopt, dopt, checkpoint_name, device_id):
+        """Restore {step, epoch, generator, discriminator, g_opt, d_opt} (comm/distributed.py:130-157)."""
+        if (checkpoint_name is not None) and (os.path.isfile(checkpoint_name)):
+            checkpoint = torch.load(checkpoint_name, map_location=device_id)
+            gopt.load_state_dict(checkpoint['g_opt'])
+            dopt.load_state_dict(checkpoint['d_opt'])
+            gmodel.load_state_dict(self._strip(checkpoint['generator']))
+            dmodel.load_state_dict(self._strip(checkpoint['discriminator']))
+            return checkpoint['step'], checkpoint['epoch']
+        return 0, 0
+
+    def DistributedModel(self, model):
+        if dist.is_available() and dist.is_initialized():
+            return DistributedModel(model)
+        return model
+
+    def DistributedOptimizer(self, optimizer, named_parameters, compression_name, op_name):
+        return optimizer

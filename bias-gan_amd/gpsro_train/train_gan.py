@@ -1,0 +1,113 @@
+"""The GAN training step of the reference loop (gpsro_train/train_gan.py:244-298)
+as a reusable object.
+
+Results-neutral work of the reference is not executed: the
+D-step does not back-propagate into the generator (its forward runs without a
+graph) and the G-step computes no discriminator weight gradients.  Everything
+that changes results is kept: both generator forwards and all discriminator
+forwards run in train mode (BatchNorm running statistics get the same number of
+momentum updates), losses and label draws follow the reference's order.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..architecture.gpsro import deeplab_gan as dxg
+from ..comm.distributed import DistributedModel
+
+
+def _unwrap(m):
+    return m.module if isinstance(m, DistributedModel) else m
+
+
+class GANTrainer:
+    def __init__(self, generator, discriminator, g_opt, d_opt, criterion_gan, criterion_regression,
+                 loss_type_gan="ModifiedMinMax", loss_weight_gan=1.0, loss_weight_regression=1.0, loss_weight_gp=10.0,
+                 enable_masks=False, generator_warmup_steps=0, g_scheduler=None, d_scheduler=None,
+                 update_frequency_generator=1, update_frequency_discriminator=1):
+        self.generator, self.discriminator = generator, discriminator
+        self.g_opt, self.d_opt = g_opt, d_opt
+        self.criterion_gan, self.criterion_regression = criterion_gan, criterion_regression
+        self.loss_type_gan = loss_type_gan
+        self.w_gan, self.w_reg, self.w_gp = loss_weight_gan, loss_weight_regression, loss_weight_gp
+        self.enable_masks = enable_masks
+        self.warmup = generator_warmup_steps
+        self.g_scheduler, self.d_scheduler = g_scheduler, d_scheduler
+        self.freq_g, self.freq_d = update_frequency_generator, update_frequency_discriminator
+        self.step_count = 0
+        self._d_pending = False
+        self._d_params = [p for p in _unwrap(discriminator).parameters()]
+
+    # -- train_gan.py:250-271 -------------------------------------------------------------
+    def d_step(self, inputs, outputs_real, labels=None, eta=None):
+        with torch.no_grad():                       # no graph through G: D's update cannot use it
+            outputs_fake = self.generator(inputs)
+        logits_real, _ = self.discriminator(outputs_real)
+        logits_fake, _ = self.discriminator(outputs_fake)
+        if labels is not None:
+            d_loss = self.criterion_gan.d_loss(logits_real, logits_fake, labels)
+        else:
+            d_loss = self.criterion_gan.d_loss(logits_real, logits_fake)
+        if self.loss_type_gan == "Wasserstein":
+            d_loss = d_loss + self.w_gp * dxg.gradient_penalty(_unwrap(self.discriminator), outputs_fake, outputs_real, eta)
+        self.d_opt.zero_grad()
+        d_loss.backward()
+        if isinstance(self.discriminator, DistributedModel):
+            self.discriminator.launch_grad_allreduce()   # overlaps with the G-step's generator forward
+        self._d_pending = True                            # Adam for D is issued by _finish_d()
+        return d_loss.detach()
+
+    def _finish_d(self):
+        if self._d_pending:
+            self.d_opt.step()
+            if self.d_scheduler is not None:
+                self.d_scheduler.step()
+            self._d_pending = False
+
+    # -- train_gan.py:273-298 -------------------------------------------------------------
+    def g_step(self, inputs, outputs_real, masks=None):
+        for p in self._d_params:                    # D is only differentiated w.r.t. its input here
+            p.requires_grad_(False)
+        try:
+            outputs_fake = self.generator(inputs)
+            # D's Adam update (and its gradient all-reduce) must land before D is used again
+            self._finish_d()
+            logits_fake, _ = self.discriminator(outputs_fake)
+            gan_loss = self.criterion_gan.g_loss(logits_fake)
+            if self.enable_masks:
+                regression_loss = self.criterion_regression(outputs_fake, outputs_real, masks)
+            else:
+                regression_loss = self.criterion_regression(outputs_fake, outputs_real)
+            if self.step_count < self.warmup:
+                g_loss = regression_loss
+            else:
+                g_loss = self.w_gan * gan_loss + self.w_reg * regression_loss
+            self.g_opt.zero_grad()
+            g_loss.backward()
+        finally:
+            for p in self._d_params:
+                p.requires_grad_(True)
+        if isinstance(self.generator, DistributedModel):
+            self.generator.launch_grad_allreduce()
+        self.g_opt.step()
+        if self.g_scheduler is not None:
+            self.g_scheduler.step()
+        return g_loss.detach()
+
+    def step(self, inputs, outputs_real, masks=None, labels=None, eta=None):
+        """One loop iteration: D-step then G-step.  Returns device scalars (no host sync).
+
+        D's optimiser step is issued inside g_step after the generator forward has
+        been enqueued: the generator forward does not read D, so under data
+        parallelism D's gradient all-reduce runs on the RCCL stream beneath it."""
+        s = self.step_count
+        train_generator = (s < self.warmup) or (s % self.freq_g == 0)            # train_gan.py:247
+        train_discriminator = (s >= self.warmup) and (s % self.freq_d == 0)      # train_gan.py:248
+        d_loss = g_loss = None
+        if train_discriminator:
+            d_loss = self.d_step(inputs, outputs_real, labels, eta)
+        if train_generator:
+            g_loss = self.g_step(inputs, outputs_real, masks)
+        self._finish_d()
+        self.step_count += 1
+        return d_loss, g_loss

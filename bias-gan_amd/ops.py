@@ -1,0 +1,498 @@
+"""torch.autograd.Function wrappers over the C ABI (include/bgamd.h).
+
+Same shape as the reference's own native-op pattern (Conv2dLocalFunction,
+architecture/gpsro/deeplab.py:9-22): forward() calls the extension and saves
+tensors, backward() calls the extension's backward entry points.  Activations
+inside a network are NHWC tensors [N,H,W,C] (C padded to a 16-byte multiple,
+pad lanes zero) whose pixel stride may exceed C (channel slices of wider
+buffers).  Parameter gradients are accumulated by the kernels straight into the
+network's flat gradient arena (runtime.Arena); the Functions return None for
+them.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .runtime import Arena, ParamSlot
+
+
+# --------------------------------------------------------------------------- helpers
+def _ld(t: torch.Tensor) -> int:
+    """Pixel stride of an NHWC tensor (strides of size-1 dims are meaningless, so
+    take it from the innermost spatial dim that has extent > 1)."""
+    n, h, w, c = t.shape
+    if w > 1:
+        return t.stride(2)
+    if h > 1:
+        return t.stride(1)
+    if n > 1:
+        return t.stride(0)
+    return c
+
+
+def _is_nhwc(t: torch.Tensor, vec: int) -> bool:
+    if t.dim() != 4 or t.data_ptr() % 16 != 0:
+        return False
+    n, h, w, c = t.shape
+    if c % vec != 0 or (c > 1 and t.stride(3) != 1):
+        return False
+    ld = _ld(t)
+    if ld < c or ld % vec != 0:
+        return False
+    if w > 1 and h > 1 and t.stride(1) != w * ld:
+        return False
+    if n > 1 and h * w > 1 and t.stride(0) != h * w * ld:
+        return False
+    return True
+
+
+def nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` if the kernels can address it as NHWC rows, else a packed copy."""
+    vec = 8 if t.dtype == torch.bfloat16 else 4
+    if _is_nhwc(t, vec):
+        return t
+    return t.contiguous()
+
+
+def ld_of(t: torch.Tensor) -> int:
+    return _ld(t)
+
+
+def rows_of(t: torch.Tensor) -> int:
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def new_act(n, h, w, c, dtype, device) -> torch.Tensor:
+    return torch.empty((n, h, w, c), dtype=dtype, device=device)
+
+
+def _f32(*shape, device):
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+def _f64(*shape, device):
+    return torch.zeros(shape, dtype=torch.float64, device=device)
+
+
+# ------------------------------------------------------------------ layout boundary
+class ToInternal(torch.autograd.Function):
+    """NCHW fp32 (module boundary, as the reference passes tensors) -> NHWC compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, cp: int, dtype: torch.dtype):
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        n, c, h, w = x.shape
+        ctx.c = c
+        y = new_act(n, h, w, cp, dtype, x.device)
+        L.call("bg_nchw_to_nhwc", L.dt(dtype), x.data_ptr(), y.data_ptr(), n, c, h * w, cp, cp)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = nhwc(g)
+        n, h, w, cp = g.shape
+        dx = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=g.device)
+        L.call("bg_nhwc_to_nchw", L.dt(g.dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), n, ctx.c, h * w)
+        return dx, None, None
+
+
+class FromInternal(torch.autograd.Function):
+    """NHWC (any compute dtype) -> NCHW fp32 with the first `c` channels."""
+
+    @staticmethod
+    def forward(ctx, x, c: int):
+        x = nhwc(x)
+        n, h, w, cp = x.shape
+        ctx.cp, ctx.dtype = cp, x.dtype
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        L.call("bg_nhwc_to_nchw", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), n, c, h * w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        n, c, h, w = g.shape
+        dx = new_act(n, h, w, ctx.cp, ctx.dtype, g.device)
+        L.call("bg_nchw_to_nhwc", L.dt(ctx.dtype), g.data_ptr(), dx.data_ptr(), n, c, h * w, ctx.cp, ctx.cp)
+        return dx, None
+
+
+# ------------------------------------------------------------------------- convolution
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d(groups=1) as implicit GEMM (bg_conv2d_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, arena: Arena, wslot: ParamSlot, bslot: Optional[ParamSlot], stride, pad, dil):
+        x = nhwc(x)
+        n, h, w, cin = x.shape
+        kp, kh, kw, cp = wslot.phys_shape
+        assert cin == cp, f"conv expects {cp} input channels (padded), got {cin}"
+        ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        y = new_act(n, ho, wo, kp, x.dtype, x.device)
+        desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), kp)
+        L.call("bg_conv2d_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot),
+               None if bslot is None else arena.master_ptr(bslot), y.data_ptr())
+        ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, bslot, stride, pad, dil, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        arena, wslot, bslot, stride, pad, dil, ho, wo = ctx.meta
+        g = nhwc(g)
+        n, h, w, cin = x.shape
+        kp, kh, kw, cp = wslot.phys_shape
+        desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(g))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(n, h, w, cin, x.dtype, x.device)
+            d2 = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, cin, ld_of(g))
+            L.call("bg_conv2d_bwd_data", d2, g.data_ptr(), arena.weight_t_ptr(wslot), dx.data_ptr())
+        if ctx.needs_input_grad[1]:
+            arena.ensure_grad(wslot)
+            dbias = None
+            if bslot is not None and ctx.needs_input_grad[2]:
+                arena.ensure_grad(bslot)
+                dbias = arena.grad_ptr(bslot)
+            L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
+        return dx, None, None, None, None, None, None, None, None
+
+
+class DwConv3x3Fn(torch.autograd.Function):
+    """Depthwise 3x3 of SeparableConv2d_same with fixed_padding folded in (bg_dwconv3x3_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, stride, dil):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
+        ho, wo = -(-h // stride), -(-w // stride)
+        y = new_act(n, ho, wo, c, x.dtype, x.device)
+        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), c)
+        L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
+        ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, stride, dil, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        arena, wslot, stride, dil, ho, wo = ctx.meta
+        g = nhwc(g)
+        n, h, w, c = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(n, h, w, c, x.dtype, x.device)
+            desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, c, ld_of(g))
+            L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), dx.data_ptr())
+        if ctx.needs_input_grad[1]:
+            arena.ensure_grad(wslot)
+            desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(g))
+            L.call("bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
+        return dx, None, None, None, None, None
+
+
+# ------------------------------------------------------- norm + residual + LeakyReLU
+class NormActFn(torch.autograd.Function):
+    """y = act( norm(x) + res ).
+
+    kind: 'batch' (nn.BatchNorm2d: batch statistics when training, running
+    statistics in eval; running stats updated in place), 'instance'
+    (nn.InstanceNorm2d defaults), 'identity'.  act: LeakyReLU(0.2) or none.
+    """
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        dev, dt = x.device, L.dt(x.dtype)
+        rows = n * h * w
+        if res is not None:
+            res = nhwc(res)
+        use_batch_stats = (kind == "batch" and training) or kind == "instance"
+        groups = n if kind == "instance" else 1
+        mean = rstd = scale = shift = None
+        if kind != "identity":
+            mean, rstd = _f32(groups, c, device=dev), _f32(groups, c, device=dev)
+            scale, shift = _f32(groups, c, device=dev), _f32(groups, c, device=dev)
+            gptr = None if gslot is None else arena.master_ptr(gslot)
+            bptr = None if bslot is None else arena.master_ptr(bslot)
+            if use_batch_stats:
+                s = _f64(2, groups, c, device=dev)
+                L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
+                upd = kind == "batch" and rmean is not None
+                L.call("bg_norm_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, bptr, eps,
+                       momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
+                       rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            else:  # BatchNorm in eval mode
+                L.call("bg_norm_eval_affine", c, gptr, bptr, rmean.data_ptr(), rvar.data_ptr(), eps, scale.data_ptr(),
+                       shift.data_ptr())
+                mean.copy_(rmean.view(1, -1))
+                rstd.copy_(torch.rsqrt(rvar + eps).view(1, -1))
+        y = new_act(n, h, w, c, x.dtype, dev)
+        L.call("bg_norm_act_fwd", dt, x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(res),
+               0 if res is None else ld_of(res), y.data_ptr(), c, rows, c, groups, int(act))
+        ctx.save_for_backward(x, y, mean, rstd)
+        ctx.meta = (arena, gslot, bslot, kind, use_batch_stats, int(act), groups, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mean, rstd = ctx.saved_tensors
+        arena, gslot, bslot, kind, batch_stats, act, groups, has_res = ctx.meta
+        g = nhwc(g)
+        n, h, w, c = x.shape
+        dev, dt = x.device, L.dt(x.dtype)
+        rows = n * h * w
+        need_dx = ctx.needs_input_grad[0]
+        need_res = has_res and ctx.needs_input_grad[1]
+        dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
+        dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
+        if kind == "identity":
+            if dx is None and dres is None:
+                return (None,) * 14
+            # dx and dres are the same tensor values: write once, alias
+            out = dx if dx is not None else dres
+            L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None,
+                   out.data_ptr(), c, None, 0, rows, c, groups, act)
+            return (out if need_dx else None, out if need_res else None) + (None,) * 12
+        want_affine_grads = gslot is not None and gslot.param.requires_grad
+        if need_dx or want_affine_grads:
+            s = _f64(2, groups, c, device=dev)
+            L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
+                   mean.data_ptr(), rstd.data_ptr(), rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
+            coef = _f32(3, groups, c, device=dev)
+            dg = db = None
+            if want_affine_grads:
+                arena.ensure_grad(gslot)
+                arena.ensure_grad(bslot)
+                dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
+            L.call("bg_norm_bwd_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
+                   None if gslot is None else arena.master_ptr(gslot), mean.data_ptr(), rstd.data_ptr(),
+                   1 if batch_stats else 0, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), dg, db)
+            if need_dx or need_res:
+                L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
+                       coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), L.ptr(dx), c, L.ptr(dres), c, rows, c,
+                       groups, act)
+        elif need_res:
+            L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None, None, 0,
+                   dres.data_ptr(), c, rows, c, groups, act)
+        return (dx, dres) + (None,) * 12
+
+
+def leaky_relu(x):
+    """Stand-alone LeakyReLU(0.2) (a Block called on a not-yet-activated input)."""
+    return NormActFn.apply(x, None, None, None, None, None, None, None, None, "identity", False, True, 0.0, 0.0)
+
+
+def add(x, res, act=False):
+    """x + res (+ LeakyReLU): the Block residual when its last unit is a conv (deeplab.py:141)."""
+    return NormActFn.apply(x, res, None, None, None, None, None, None, None, "identity", False, act, 0.0, 0.0)
+
+
+class ForkFn(torch.autograd.Function):
+    """One producer, k consumers: backward sums the k gradients with our kernel
+    (instead of autograd's implicit torch.add)."""
+
+    @staticmethod
+    def forward(ctx, x, k: int):
+        ctx.k = k
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [nhwc(g) for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            n, h, w, c = acc.shape
+            out = new_act(n, h, w, c, acc.dtype, acc.device)
+            L.call("bg_norm_act_fwd", L.dt(acc.dtype), acc.data_ptr(), ld_of(acc), None, None, g.data_ptr(), ld_of(g),
+                   out.data_ptr(), c, n * h * w, c, 1, 0)
+            acc = out
+        return acc, None
+
+
+def fork(x, k: int):
+    return ForkFn.apply(x, k)
+
+
+# -------------------------------------------------------------- resampling / pooling
+class ResizeBilinearFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=True) (deeplab.py:375,379,663)."""
+
+    @staticmethod
+    def forward(ctx, x, ho: int, wo: int, out_dtype: Optional[torch.dtype]):
+        x = nhwc(x)
+        n, hi, wi, c = x.shape
+        out_dtype = out_dtype or x.dtype
+        y = new_act(n, ho, wo, c, out_dtype, x.device)
+        L.call("bg_resize_bilinear_fwd", L.dt(x.dtype), L.dt(out_dtype), x.data_ptr(), ld_of(x), y.data_ptr(), c, n, hi,
+               wi, ho, wo, c)
+        ctx.meta = (n, hi, wi, ho, wo, c, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, hi, wi, ho, wo, c, in_dtype = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n, hi, wi, c, in_dtype, g.device)
+        if hi == 1 and wi == 1:
+            # broadcast forward -> plain column sum backward
+            acc = _f32(n, c, device=g.device)
+            L.call("bg_colsum", L.dt(g.dtype), g.data_ptr(), ld_of(g), n * ho * wo, c, n, 1.0, acc.data_ptr())
+            L.call("bg_cast_rows", L.F32, L.dt(in_dtype), acc.data_ptr(), c, dx.data_ptr(), c, n, c)
+        else:
+            L.call("bg_resize_bilinear_bwd", L.dt(g.dtype), L.dt(in_dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), c, n,
+                   hi, wi, ho, wo, c)
+        return dx, None, None, None
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) (deeplab.py:621)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        acc = _f32(n, c, device=x.device)
+        L.call("bg_colsum", L.dt(x.dtype), x.data_ptr(), ld_of(x), n * h * w, c, n, 1.0 / (h * w), acc.data_ptr())
+        y = new_act(n, 1, 1, c, x.dtype, x.device)
+        L.call("bg_cast_rows", L.F32, L.dt(x.dtype), acc.data_ptr(), c, y.data_ptr(), c, n, c)
+        ctx.meta = (n, h, w, c, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c, dtype = ctx.meta
+        g = g.contiguous()
+        gf = _f32(n, c, device=g.device)
+        L.call("bg_cast_rows", L.dt(g.dtype), L.F32, g.data_ptr(), c, gf.data_ptr(), c, n, c)
+        dx = new_act(n, h, w, c, dtype, g.device)
+        L.call("bg_broadcast_rows", L.dt(dtype), gf.data_ptr(), 1.0 / (h * w), dx.data_ptr(), c, n * h * w, c, n)
+        return dx
+
+
+class ConcatFn(torch.autograd.Function):
+    """torch.cat(dim=1) of the reference (deeplab.py:377,664) = channel concat in NHWC."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [nhwc(x) for x in xs]
+        n, h, w, _ = xs[0].shape
+        cs = [x.shape[3] for x in xs]
+        out = new_act(n, h, w, sum(cs), xs[0].dtype, xs[0].device)
+        off = 0
+        dt = L.dt(out.dtype)
+        for x, c in zip(xs, cs):
+            L.call("bg_cast_rows", dt, dt, x.data_ptr(), ld_of(x), out.data_ptr() + off * out.element_size(), sum(cs),
+                   n * h * w, c)
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(g[..., off:off + c])  # zero-copy channel slices; consumers honour the pixel stride
+            off += c
+        return tuple(outs)
+
+
+def concat(*xs):
+    return ConcatFn.apply(*xs)
+
+
+# ---------------------------------------------------------------------------- head
+class LinearHeadFn(torch.autograd.Function):
+    """reshape(N,-1) + nn.Linear(F,1) on the NCHW-ordered features (deeplab_gan.py:32-35)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, arena: Arena, wslot: ParamSlot, bslot: ParamSlot):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        assert wslot.numel == c * h * w, "Linear head in_features must be C*H*W of the feature map"
+        logits = _f32(n, 1, device=x.device)
+        L.call("bg_linear_head_fwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), arena.master_ptr(wslot),
+               arena.master_ptr(bslot), logits.data_ptr(), n, h * w, c)
+        ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, bslot)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        arena, wslot, bslot = ctx.meta
+        n, h, w, c = x.shape
+        g = g.contiguous().float()
+        dx = new_act(n, h, w, c, x.dtype, x.device) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            arena.ensure_grad(wslot)
+            arena.ensure_grad(bslot)
+            dw, db = arena.grad_ptr(wslot), arena.grad_ptr(bslot)
+        L.call("bg_linear_head_bwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), arena.master_ptr(wslot), g.data_ptr(), L.ptr(dx),
+               c, dw, db, n, h * w, c)
+        return dx, None, None, None, None, None
+
+
+# -------------------------------------------------------------------------- losses
+class BCEWithLogitsFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss() on [N,1] logits (utils/losses.py:138)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = logits.contiguous().float()
+        t = target.contiguous().float()
+        loss = _f32(1, device=x.device)
+        dx = torch.empty_like(x)
+        L.call("bg_bce_logits", x.data_ptr(), t.data_ptr(), x.numel(), loss.data_ptr(), dx.data_ptr())
+        ctx.save_for_backward(dx)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None  # N scalars of glue
+
+
+class L1LossFn(torch.autograd.Function):
+    """mean(|p-t| * w) or sum(|p-t| w)/(sum w + eps)  (nn.L1Loss / L1LossWeighted, losses.py:101-112)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weights, inv_norm: float):
+        p = pred.contiguous().float()
+        t = target.contiguous().float()
+        wt = None if weights is None else weights.contiguous().float()
+        loss = _f32(1, device=p.device)
+        L.call("bg_l1_loss_fwd", p.data_ptr(), t.data_ptr(), L.ptr(wt), p.numel(), inv_norm, loss.data_ptr())
+        ctx.save_for_backward(p, t, wt)
+        ctx.inv_norm = inv_norm
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, wt = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        coef = g.reshape(1).float().contiguous()
+        L.call("bg_l1_loss_bwd", p.data_ptr(), t.data_ptr(), L.ptr(wt), p.numel(), ctx.inv_norm, coef.data_ptr(),
+               dp.data_ptr())
+        return dp, None, None, None
+
+
+def gp_penalty_value(grad_nchw: torch.Tensor) -> torch.Tensor:
+    """mean over N,H,W of (||g||_2 over C - 1)^2 (deeplab_gan.py:112); a constant (no graph)."""
+    g = grad_nchw.contiguous().float()
+    n, c, h, w = g.shape
+    out = _f32(1, device=g.device)
+    L.call("bg_gp_penalty", g.data_ptr(), n, c, h * w, 1.0 / (n * h * w), out.data_ptr())
+    return out.view(())

@@ -1,0 +1,263 @@
+"""Parameter arenas and the module base class.
+
+MI355X-first memory layout for the model state: every trainable tensor of a
+network lives in ONE flat fp32 arena (plus one flat gradient arena and, for the
+bf16 path, one flat bf16 copy and one flat CRSK-transposed copy for the
+data-gradient GEMMs).  That gives
+  * one fused Adam launch per network instead of ~500,
+  * one contiguous buffer to all-reduce over RCCL in a few large messages,
+  * conv weights stored the way the MFMA kernels read them (KRSC), while the
+    nn.Parameter the user sees keeps the reference's [Cout,Cin,KH,KW] shape as a
+    permuted VIEW of the arena (so state_dict keys/shapes interchange with
+    reference checkpoints; deeplab.py / deeplab_gan.py define the names).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def default_compute_dtype() -> torch.dtype:
+    v = os.environ.get("BGAMD_DTYPE", "bf16").lower()
+    return torch.float32 if v in ("f32", "fp32", "float32") else torch.bfloat16
+
+
+def vec_of(dtype: torch.dtype) -> int:
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def pad_to(c: int, v: int) -> int:
+    return (c + v - 1) // v * v
+
+
+class ParamSlot:
+    """Where one nn.Parameter lives inside the arenas."""
+    __slots__ = ("name", "param", "kind", "off", "numel", "phys_shape", "t_off", "krsc")
+
+    def __init__(self, name, param, kind, phys_shape):
+        self.name, self.param, self.kind, self.phys_shape = name, param, kind, tuple(phys_shape)
+        self.numel = 1
+        for s in phys_shape:
+            self.numel *= s
+        self.off = -1
+        self.t_off = -1   # offset inside the transposed (CRSK) arena, dense convs only
+        self.krsc = None  # (K, RS, C) for dense convs
+
+
+_ARENA_OF = {}  # id(param) -> weakref to its arena
+
+
+def arena_of(p):
+    """The arena a Parameter currently lives in (None before the first GPU forward)."""
+    r = _ARENA_OF.get(id(p))
+    a = None if r is None else r()
+    if a is not None and a.by_param.get(id(p)) is not None and a.by_param[id(p)].param is p:
+        return a
+    return None
+
+
+class Arena:
+    """Flat storage for the parameters of one network (see module docstring)."""
+
+    def __init__(self, root: nn.Module, compute_dtype: torch.dtype):
+        self.compute_dtype = compute_dtype
+        self.slots: List[ParamSlot] = []
+        self.by_param: Dict[int, ParamSlot] = {}
+        dev = None
+        for name, mod in root.named_modules():
+            spec = getattr(mod, "_bg_param_layout", None)
+            for pname, p in mod._parameters.items():
+                if p is None:
+                    continue
+                dev = p.device if dev is None else dev
+                if p.device != dev:
+                    raise RuntimeError("bias_gan_amd: all parameters of a network must live on one device")
+                full = f"{name}.{pname}" if name else pname
+                kind, phys = ("plain", tuple(p.shape))
+                if spec is not None and pname in spec:
+                    kind, phys = spec[pname](p, vec_of(compute_dtype))
+                slot = ParamSlot(full, p, kind, phys)
+                self.slots.append(slot)
+                self.by_param[id(p)] = slot
+        if dev is None:
+            raise RuntimeError("bias_gan_amd: module has no parameters")
+        self.device = dev
+        off = 0
+        t_off = 0
+        for s in self.slots:
+            s.off = off
+            off += pad_to(s.numel, 64)  # 256-byte aligned segments
+            if s.kind == "conv":
+                k, r, q, c = s.phys_shape
+                s.krsc = (k, r * q, c)
+                s.t_off = t_off
+                t_off += pad_to(s.numel, 64)
+        self.numel = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.lp = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        self.tr = torch.zeros(max(t_off, 1), dtype=compute_dtype, device=dev)
+        tbl = [[s.off, s.t_off, s.krsc[0], s.krsc[1], s.krsc[2]] for s in self.slots if s.kind == "conv"]
+        self.tr_tbl = torch.tensor(tbl if tbl else [[0, 0, 0, 0, 0]], dtype=torch.int64, device=dev)
+        self.tr_layers = len(tbl)
+        self.tr_max = max([s.numel for s in self.slots if s.kind == "conv"] + [1])
+        # move the current values in and re-point the Parameters at arena views
+        with torch.no_grad():
+            for s in self.slots:
+                view = self._view(self.master, s)
+                view.copy_(s.param.data)
+                s.param.data = view
+                s.param.grad = None
+        self._synced_version = -1
+        self.ddp = None
+        self.attach_grads()
+        import weakref
+        for s in self.slots:
+            _ARENA_OF[id(s.param)] = weakref.ref(self)
+
+    # -- views ---------------------------------------------------------------------
+    def _view(self, flat: torch.Tensor, s: ParamSlot) -> torch.Tensor:
+        seg = flat[s.off:s.off + s.numel]
+        p = s.param
+        if s.kind == "conv":       # arena [Kp,R,S,Cp] -> logical [K,C,R,S]
+            k, c = p.shape[0], p.shape[1]
+            return seg.view(s.phys_shape).permute(0, 3, 1, 2)[:k, :c]
+        if s.kind == "dw":         # arena [R,S,Cp] -> logical [C,1,R,S]
+            c = p.shape[0]
+            return seg.view(s.phys_shape).permute(2, 0, 1)[:c].unsqueeze(1)
+        if s.kind == "vec":        # arena [Cp] -> logical [C]
+            return seg[:p.shape[0]]
+        return seg.view(p.shape)
+
+    def attach_grads(self):
+        """Make every Parameter's .grad a view of the gradient arena."""
+        for s in self.slots:
+            if s.param.requires_grad:
+                s.param.grad = self._view(self.grad, s)
+
+    def zero_grad(self):
+        L.call("bg_fill_f32", self.grad.data_ptr(), 0.0, self.numel)
+
+    def ensure_grad(self, s: ParamSlot):
+        """Called from a backward before it accumulates into the arena.  If a
+        foreign optimiser set .grad to None (zero_grad(set_to_none=True)), zero
+        this parameter's segment and re-attach the view."""
+        if arena_of(s.param) is not self:
+            raise RuntimeError("bias_gan_amd: backward through a graph whose parameter arena was rebuilt "
+                               "(module moved / dtype changed / sub-module arena replaced after the forward pass)")
+        g = s.param.grad
+        if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * s.off:
+            L.call("bg_fill_f32", self.grad.data_ptr() + 4 * s.off, 0.0, s.numel)
+            s.param.grad = self._view(self.grad, s)
+
+    # -- low-precision / transposed copies ---------------------------------------------
+    def weights_changed(self):
+        self._synced_version = -1
+
+    def sync(self):
+        """Refresh the bf16 copy and the CRSK copies if the master arena changed
+        (torch-side writes bump the tensor version; our Adam calls refresh_copies())."""
+        v = self.master._version
+        if v != self._synced_version:
+            self.refresh_copies(cast=True)
+            self._synced_version = v
+
+    def refresh_copies(self, cast: bool):
+        if self.lp is not None and cast:
+            L.call("bg_cast_f32_to_bf16", self.master.data_ptr(), self.lp.data_ptr(), self.numel)
+        if self.tr_layers:
+            src = self.lp if self.lp is not None else self.master
+            L.call("bg_transpose_krsc", L.dt(self.compute_dtype), src.data_ptr(), self.tr.data_ptr(),
+                   self.tr_tbl.data_ptr(), self.tr_layers, self.tr_max)
+
+    def weight_ptr(self, s: ParamSlot) -> int:
+        """Device pointer of the compute-dtype copy of a parameter (KRSC / [R,S,C])."""
+        if self.lp is not None:
+            return self.lp.data_ptr() + 2 * s.off
+        return self.master.data_ptr() + 4 * s.off
+
+    def weight_t_ptr(self, s: ParamSlot) -> int:
+        return self.tr.data_ptr() + self.tr.element_size() * s.t_off
+
+    def master_ptr(self, s: ParamSlot) -> int:
+        return self.master.data_ptr() + 4 * s.off
+
+    def grad_ptr(self, s: ParamSlot) -> int:
+        return self.grad.data_ptr() + 4 * s.off
+
+
+class BGModule(nn.Module):
+    """Base of every module in this package: lazily (re)builds the arena of the
+    root it is called through, and invalidates it when .to()/.cuda() moves data."""
+
+    _bg_arena: Optional[Arena] = None
+    _bg_dtype: Optional[torch.dtype] = None
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        # The OUTERMOST module that is called builds the arena for its whole
+        # subtree before any child runs (children called through it find it ready).
+        self.register_forward_pre_hook(BGModule._ensure_arena_hook)
+
+    @staticmethod
+    def _ensure_arena_hook(mod, inputs):
+        mod.arena()
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        for m in self.modules():
+            if isinstance(m, BGModule):
+                object.__setattr__(m, "_bg_arena", None)
+        return out
+
+    def compute_dtype(self) -> torch.dtype:
+        return self._bg_dtype or default_compute_dtype()
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        for m in self.modules():
+            if isinstance(m, BGModule):
+                object.__setattr__(m, "_bg_dtype", dtype)
+                object.__setattr__(m, "_bg_arena", None)
+        return self
+
+    def arena(self) -> Arena:
+        """The arena this module's parameters live in (built on first use, with
+        this module as root if no ancestor built one)."""
+        a = self._bg_arena
+        if a is None:
+            first = next(self.parameters(), None)
+            if first is None or first.device.type != "cuda":
+                raise RuntimeError("bias_gan_amd: the HIP path needs the module on a GPU (call .to('cuda')); "
+                                   "there is no CPU fallback")
+            a = Arena(self, self.compute_dtype())
+            for m in self.modules():
+                if isinstance(m, BGModule):
+                    object.__setattr__(m, "_bg_arena", a)
+        a.sync()
+        return a
+
+    def slot(self, p: nn.Parameter) -> ParamSlot:
+        return self.arena().by_param[id(p)]
+
+    def flush_counters(self):
+        """Fold the host-side BatchNorm forward counts into num_batches_tracked."""
+        for m in self.modules():
+            pend = m.__dict__.get("_bg_nbt_pending", 0)
+            if pend and getattr(m, "num_batches_tracked", None) is not None:
+                m.num_batches_tracked += pend
+                m.__dict__["_bg_nbt_pending"] = 0
+
+    def state_dict(self, *a, **kw):
+        self.flush_counters()
+        return super().state_dict(*a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        if self._bg_arena is not None:
+            self._bg_arena.weights_changed()
+        return out

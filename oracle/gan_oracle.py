@@ -237,12 +237,24 @@ class NormCtx:
     'batch' = nn.BatchNorm2d defaults, 'instance' = nn.InstanceNorm2d defaults
     (no affine, no running stats), 'identity' = pass-through."""
 
-    def __init__(self, kind: str = "batch", training: bool = True, update_stats: bool = True):
+    def __init__(self, kind: str = "batch", training: bool = True, update_stats: bool = True, bf16: bool = False):
         assert kind in ("batch", "instance", "identity")
         self.kind, self.training, self.update_stats = kind, training, update_stats
+        # bf16=True emulates the storage roundings of the BG_BF16 kernel path (activations
+        # and conv weights held in bfloat16, all arithmetic and statistics in fp32) so the
+        # GPU bf16 forward can be checked against a CPU evaluation with the same rounding
+        # points.  Rounding is straight-through for autograd.
+        self.bf16 = bf16
+
+    def q(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.bf16:
+            return x
+        return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
 
 
 def norm(P: State, key: str, x: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
+    """Normaliser WITHOUT storage rounding: callers round after the fused
+    norm(+residual)(+activation), like the kernels do."""
     if ctx.kind == "identity":
         return x
     if ctx.kind == "instance":
@@ -263,10 +275,11 @@ def norm(P: State, key: str, x: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
     return F.batch_norm(x, rm, rv, g, b, False, BN_MOMENTUM, BN_EPS)
 
 
-def sepconv_same(P: State, key: str, x: torch.Tensor, stride: int, dil: int) -> torch.Tensor:
+def sepconv_same(P: State, key: str, x: torch.Tensor, stride: int, dil: int, ctx: Optional[NormCtx] = None) -> torch.Tensor:
     """SeparableConv2d_same: zero-pad by k_eff-1 split (beg=total//2, end=rest),
     depthwise 3x3 (no bias), pointwise 1x1 (no bias), nothing in between
     (deeplab.py:66-87)."""
+    q = ctx.q if ctx is not None else (lambda t: t)
     wd, wp = P[key + ".conv1.weight"], P[key + ".pointwise.weight"]
     k = wd.shape[-1]
     keff = k + (k - 1) * (dil - 1)
@@ -274,30 +287,44 @@ def sepconv_same(P: State, key: str, x: torch.Tensor, stride: int, dil: int) -> 
     beg = tot // 2
     end = tot - beg
     x = F.pad(x, (beg, end, beg, end))
-    x = F.conv2d(x, wd, None, stride, 0, dil, groups=wd.shape[0])
-    return F.conv2d(x, wp)
+    x = q(F.conv2d(x, q(wd), None, stride, 0, dil, groups=wd.shape[0]))
+    return q(F.conv2d(x, q(wp)))
 
 
 def block(P: State, bp: str, cfg: dict, x: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
     """One Block (deeplab.py:90-143).  ``x`` is NOT mutated here; instead the
     aliasing of the reference's in-place first LeakyReLU is made explicit: when
     the block starts with it, both the unit chain and the skip path consume
-    ``leaky_relu(x)``."""
-    a = lrelu(x) if cfg["start_relu"] else x
+    ``leaky_relu(x)``.  The returned sum is not storage-rounded (ctx.bf16): its
+    consumer rounds after its own fused activation, as the kernels do."""
+    q = ctx.q
+    a = q(lrelu(x)) if cfg["start_relu"] else x
     h = a
     units = block_units(cfg)
-    for u in units:
-        if u["kind"] == "relu":
-            if u["idx"] == 0 and cfg["start_relu"]:
-                continue  # already applied to `a`
-            h = lrelu(h)
-        elif u["kind"] == "sep":
-            h = sepconv_same(P, bp + f"rep.{u['idx']}", h, u["stride"], u["dil"])
+    i = 1 if cfg["start_relu"] else 0
+    tail = None
+    while i < len(units):
+        u = units[i]
+        if u["kind"] == "sep":
+            h = sepconv_same(P, bp + f"rep.{u['idx']}", h, u["stride"], u["dil"], ctx)
+            i += 1
+        elif u["kind"] == "relu":
+            h = q(lrelu(h))
+            i += 1
         else:
             h = norm(P, bp + f"rep.{u['idx']}", h, ctx)
+            if i == len(units) - 1:
+                tail = h
+                break
+            if units[i + 1]["kind"] == "relu":  # fused normalise + activate, one rounding
+                h = q(lrelu(h))
+                i += 2
+            else:
+                h = q(h)
+                i += 1
     if cfg["cin"] != cfg["cout"] or cfg["stride"] != 1:
-        s = F.conv2d(a, P[bp + "skip.weight"], None, cfg["stride"])
-        s = norm(P, bp + "skipbn", s, ctx)
+        s = q(F.conv2d(a, q(P[bp + "skip.weight"]), None, cfg["stride"]))
+        s = q(norm(P, bp + "skipbn", s, ctx))
     else:
         s = a
     return h + s
@@ -305,21 +332,23 @@ def block(P: State, bp: str, cfg: dict, x: torch.Tensor, ctx: NormCtx) -> torch.
 
 def xception(P: State, prefix: str, x: torch.Tensor, ctx: NormCtx, os: int = 16):
     """Xception.forward (deeplab.py:231-278) -> (features, low_level_feat)."""
-    x = F.conv2d(x, P[prefix + "conv1.weight"], None, 2, 1)
-    x = lrelu(norm(P, prefix + "bn1", x, ctx))
-    x = F.conv2d(x, P[prefix + "conv2.weight"], None, 1, 1)
-    x = lrelu(norm(P, prefix + "bn2", x, ctx))
+    q = ctx.q
+    x = q(F.conv2d(q(x), q(P[prefix + "conv1.weight"]), None, 2, 1))
+    x = q(lrelu(norm(P, prefix + "bn1", x, ctx)))
+    x = q(F.conv2d(x, q(P[prefix + "conv2.weight"]), None, 1, 1))
+    x = q(lrelu(norm(P, prefix + "bn2", x, ctx)))
     low = None
     for cfg in xception_block_table(os):
         x = block(P, prefix + cfg["name"] + ".", cfg, x, ctx)
         if cfg["name"] == "block1":
             # block2's in-place LeakyReLU later activates this very tensor
             # (deeplab.py:242 aliases it), so the skip feature is activated.
-            low = lrelu(x)
+            low = q(lrelu(x))
+    x = q(x)  # block20's sum feeds conv3 without an activation in between
     rate = 2 if os == 16 else 4
     for name in ("3", "4", "5"):
-        x = sepconv_same(P, prefix + f"conv{name}", x, 1, rate)
-        x = lrelu(norm(P, prefix + f"bn{name}", x, ctx))
+        x = sepconv_same(P, prefix + f"conv{name}", x, 1, rate, ctx)
+        x = q(lrelu(norm(P, prefix + f"bn{name}", x, ctx)))
     return x, low
 
 
@@ -330,28 +359,29 @@ def bilinear_ac(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
 
 def deeplab(P: State, prefix: str, x_in: torch.Tensor, ctx: NormCtx, os: int = 16) -> torch.Tensor:
     """DeepLabv3_plus.forward with the Interpolate upsampler (deeplab.py:654-684,374-381)."""
+    q = ctx.q
     rates = [1, 6, 12, 18] if os == 16 else [1, 12, 24, 36]
     x, low = xception(P, prefix + "xception_features.", x_in, ctx, os)
     branches = []
     for i, r in zip((1, 2, 3, 4), rates):
-        w = P[prefix + f"aspp{i}.atrous_convolution.weight"]
-        b = F.conv2d(x, w, None, 1, 0 if r == 1 else r, r)
-        branches.append(lrelu(norm(P, prefix + f"aspp{i}.bn", b, ctx)))
-    g = x.mean(dim=(2, 3), keepdim=True)
-    g = F.conv2d(g, P[prefix + "global_avg_pool.1.weight"])
-    g = lrelu(norm(P, prefix + "global_avg_pool.2", g, ctx))
-    branches.append(bilinear_ac(g, branches[-1].shape[2:]))
+        w = q(P[prefix + f"aspp{i}.atrous_convolution.weight"])
+        b = q(F.conv2d(x, w, None, 1, 0 if r == 1 else r, r))
+        branches.append(q(lrelu(norm(P, prefix + f"aspp{i}.bn", b, ctx))))
+    g = q(x.mean(dim=(2, 3), keepdim=True))
+    g = q(F.conv2d(g, q(P[prefix + "global_avg_pool.1.weight"])))
+    g = q(lrelu(norm(P, prefix + "global_avg_pool.2", g, ctx)))
+    branches.append(q(bilinear_ac(g, branches[-1].shape[2:])))
     x = torch.cat(branches, dim=1)
-    x = lrelu(norm(P, prefix + "bn1", F.conv2d(x, P[prefix + "conv1.weight"]), ctx))
-    low = lrelu(norm(P, prefix + "bn2", F.conv2d(low, P[prefix + "conv2.weight"]), ctx))
+    x = q(lrelu(norm(P, prefix + "bn1", q(F.conv2d(x, q(P[prefix + "conv1.weight"]))), ctx)))
+    low = q(lrelu(norm(P, prefix + "bn2", q(F.conv2d(low, q(P[prefix + "conv2.weight"]))), ctx)))
     H, W = x_in.shape[2], x_in.shape[3]
-    x = bilinear_ac(x, (ceil_div(H, 4), ceil_div(W, 4)))
+    x = q(bilinear_ac(x, (ceil_div(H, 4), ceil_div(W, 4))))
     x = torch.cat((x, low), dim=1)
     up = prefix + "upsample.last_conv."
-    x = lrelu(norm(P, up + "1", F.conv2d(x, P[up + "0.weight"], None, 1, 1), ctx))
-    x = lrelu(norm(P, up + "4", F.conv2d(x, P[up + "3.weight"], None, 1, 1), ctx))
-    x = F.conv2d(x, P[up + "6.weight"], P[up + "6.bias"])
-    return bilinear_ac(x, (H, W))
+    x = q(lrelu(norm(P, up + "1", q(F.conv2d(x, q(P[up + "0.weight"]), None, 1, 1)), ctx)))
+    x = q(lrelu(norm(P, up + "4", q(F.conv2d(x, q(P[up + "3.weight"]), None, 1, 1)), ctx)))
+    x = q(F.conv2d(x, q(P[up + "6.weight"]), P[up + "6.bias"]))
+    return bilinear_ac(x, (H, W))  # the last resize writes fp32
 
 
 def generator(P: State, x: torch.Tensor, ctx: NormCtx, noise: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -192,7 +192,7 @@ def test_dwconv(case, dtype):
 @pytest.mark.parametrize("act,with_res", [(1, False), (0, True), (1, True)])
 def test_norm_act(dtype, mode, act, with_res):
     n, h, w, c = 3, 7, 9, 24
-    x = rnd((n, c, h, w), 8, dtype, 2.0) + 0.5
+    x = (rnd((n, c, h, w), 8, dtype, 2.0) + 0.5).to(dtype).float()  # keep it representable in `dtype`
     res = rnd((n, c, h, w), 9, dtype)
     gamma = torch.rand(c, generator=torch.Generator().manual_seed(1)) + 0.5
     beta = torch.randn(c, generator=torch.Generator().manual_seed(2)) * 0.2
@@ -365,7 +365,8 @@ def test_linear_head(dtype):
     ref.backward(dl)
     dxb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
     dw, db = torch.zeros(1, c * h * w, device=DEV), torch.zeros(1, device=DEV)
-    L.call("bg_linear_head_bwd", L.dt(dtype), xv.data_ptr(), c, w_d.data_ptr(), dl.to(DEV).data_ptr(), dxb.data_ptr(), c,
+    dl_d = dl.to(DEV)
+    L.call("bg_linear_head_bwd", L.dt(dtype), xv.data_ptr(), c, w_d.data_ptr(), dl_d.data_ptr(), dxb.data_ptr(), c,
            dw.data_ptr(), db.data_ptr(), n, h * w, c)
     assert_close(from_nhwc(dxb, c), xr.grad, tol(dtype), "head dx")
     assert_close(dw.cpu(), wr.grad, 1e-5, "head dw")
@@ -377,7 +378,8 @@ def test_losses():
     x = torch.randn(n, 1) * 3
     y = torch.rand(n, 1)
     loss, dx = torch.zeros(1, device=DEV), torch.zeros(n, 1, device=DEV)
-    L.call("bg_bce_logits", x.to(DEV).data_ptr(), y.to(DEV).data_ptr(), n, loss.data_ptr(), dx.data_ptr())
+    xd, yd = x.to(DEV), y.to(DEV)
+    L.call("bg_bce_logits", xd.data_ptr(), yd.data_ptr(), n, loss.data_ptr(), dx.data_ptr())
     xr = x.clone().requires_grad_(True)
     ref = F.binary_cross_entropy_with_logits(xr, y)
     ref.backward()
@@ -401,7 +403,8 @@ def test_losses():
         assert_close(dp.cpu(), pr.grad, 1e-6, "l1 grad")
     g = torch.randn(2, 6, 5, 4)
     gp = torch.zeros(1, device=DEV)
-    L.call("bg_gp_penalty", g.to(DEV).data_ptr(), 2, 6, 20, 1.0 / 40, gp.data_ptr())
+    gd = g.to(DEV)
+    L.call("bg_gp_penalty", gd.data_ptr(), 2, 6, 20, 1.0 / 40, gp.data_ptr())
     assert_close(gp.cpu(), ((g.norm(2, dim=1) - 1) ** 2).mean().reshape(1), 1e-5, "gp")
 
 
@@ -416,7 +419,8 @@ def test_adam_matches_torch():
         for t, g in enumerate((g1, g2), 1):
             pr.grad = g.clone()
             opt.step()
-            L.call("bg_adam_step", p.data_ptr(), (2 * g).to(DEV).data_ptr(), m.data_ptr(), v.data_ptr(), plp.data_ptr(), n,
+            gdev = (2 * g).to(DEV)
+            L.call("bg_adam_step", p.data_ptr(), gdev.data_ptr(), m.data_ptr(), v.data_ptr(), plp.data_ptr(), n,
                    1e-3, 0.9, 0.999, 1e-8, 1e-2, decoupled, 1 - 0.9 ** t, 1 - 0.999 ** t, 0.5)
         assert_close(p.cpu(), pr.detach(), 1e-6, "adam")
         assert torch.equal(plp.cpu(), p.cpu().to(torch.bfloat16))
