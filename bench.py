@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- climate-field samples/s for one full G+D training step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric): 1152x768x16 synthetic fields, batch 8 per GPU,
+Generator = noise-free DeepLabv3+/Xception-65 with the Interpolate upsampler,
+Discriminator = Xception-65 + Linear head, ModifiedMinMax + L1 (weights 1/1),
+Adam(lr 1e-4, eps 1e-8, wd 1e-5), bf16 activations/weights with fp32
+accumulation, fp32 master weights / statistics / optimiser.  One "step" = one
+loop iteration of the reference (train_gan.py:244-298): D-step (G forward, two D
+forwards, D backward, Adam) then G-step (G forward, D forward, backward through D
+and G, Adam).  Data parallel over N GPUs: one process per GPU, gradients
+all-reduced over RCCL on a side stream, weak scaling.
+
+Rank 0 prints ONE JSON line; see README/DESIGN.md for the extra objects:
+  roofline     per-kernel durations measured with HIP events (one extra,
+               un-timed profiled step) for the dominant MFMA kernel family
+  cpu_baseline the CPU oracle (a port of the reference path on PyTorch CPU ops)
+               timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+# forward GMAC per sample at 1152x768x16 (G 313.9, D 190.2);
+# a step needs 4 G-units + 8 D-units  ->  2776.9 GMAC = 5.5538 TFLOP per sample.
+W_ALG_TFLOP = {(1152, 768, 16): 2.0 * (4 * 313.9 + 8 * 190.2) * 1e-3,
+               (256, 256, 16): 2.0 * (4 * 23.25 + 8 * 14.09) * 1e-3,
+               (64, 64, 4): 2.0 * (4 * 1.439 + 8 * 0.866) * 1e-3}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1152)
+    ap.add_argument("--width", type=int, default=768)
+    ap.add_argument("--channels", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_batch(n, c, h, w, seed, device):
+    """inputs ~ N(0,1), label = input + 0.1 N(0,1), generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn((n, c, h, w), generator=g, device=device)
+    y = x + 0.1 * torch.randn((n, c, h, w), generator=g, device=device)
+    return x, y
+
+
+def cpu_baseline(c, h, w):
+    """Time the CPU oracle (a functional port of the reference path on PyTorch CPU
+    ops, same oneDNN convolutions the reference would hit) on a bounded sample of
+    the SAME workload: ONE full G+D iteration at the full field size, batch 2 (the
+    smallest batch BatchNorm accepts on the 1x1 global-pool branch), on the box's
+    host cores.  About 20 s."""
+    from oracle import gan_oracle as orc
+    # the box's CPU share, not the host's core count (a 1-GPU box gets 16 cores)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("BG_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    hs, ws, n = h, w, 2
+    gspec = orc.generator_spec(c, c, 0, "batch")
+    dspec = orc.discriminator_spec(c, hs, ws, "batch")
+    st = orc.GANStep(orc.fill_state(gspec, 1), orc.fill_state(dspec, 2), orc.trainable_keys(gspec),
+                     orc.trainable_keys(dspec), "batch", "ModifiedMinMax")
+    x, y = orc.synthetic_fields(n, c, hs, ws, 333)
+    torch.manual_seed(333)
+    print(f"[bench] cpu_baseline: timing the oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    st.step(x, y)
+    dt = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline: {dt:.1f} s", file=sys.stderr, flush=True)
+    frac = (hs * ws) / float(h * w)
+    return {"value": n / dt * frac, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one G+D iteration of oracle/gan_oracle.py (fp32, PyTorch CPU ops) at {hs}x{ws}x{c}, batch {n}: "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import bias_gan_amd  # noqa: F401
+    from bias_gan_amd import _lib as L
+    from bias_gan_amd.architecture.gpsro import deeplab_gan as dxg
+    from bias_gan_amd.comm.distributed import comm as distcomm
+    from bias_gan_amd.gpsro_train.train_gan import GANTrainer
+    from bias_gan_amd.utils import losses
+    from bias_gan_amd.utils import parsing_helpers as ph
+    L.load()  # fail loudly if the HIP library is missing
+
+    comm = distcomm(mode="dummy" if world == 1 else "torchrun")
+    seed = 333 + 7 * rank                      # the reference's seed rule (train_gan.py:56)
+    torch.manual_seed(seed)
+    c, h, w, n = args.channels, args.height, args.width, args.batch
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(333)                     # identical initial weights on every rank (DDP also broadcasts)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the constructors print like the reference's; stdout is for the JSON line
+        G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, os=16, pretrained=False, normalizer=nn.BatchNorm2d,
+                          compute_dtype=dtype).to(device)
+        D = dxg.Discriminator(n_input=c, os=16, pretrained=False, normalizer=nn.BatchNorm2d, input_size=(h, w),
+                              compute_dtype=dtype).to(device)
+    torch.manual_seed(seed)
+    G.train(), D.train()
+    g_opt = ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5)
+    d_opt = ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5)
+    Gd, Dd = comm.DistributedModel(G), comm.DistributedModel(D)
+    crit = losses.GANLoss("ModifiedMinMax", n, device)
+    trainer = GANTrainer(Gd, Dd, g_opt, d_opt, crit, losses.L1Loss())
+
+    batches = [synthetic_batch(n, c, h, w, seed + 1000 * i, device) for i in range(2)]
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"models built, {args.warmup} warm-up steps")
+    for i in range(args.warmup):
+        trainer.step(*batches[i % 2])
+    sync_all()
+    note(f"timing {args.steps} steps")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        d_loss, g_loss = trainer.step(*batches[i % 2])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    note(f"done: {1e3 * elapsed / args.steps:.1f} ms/step")
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    d_loss, g_loss = float(d_loss), float(g_loss)
+    assert d_loss == d_loss and g_loss == g_loss, "training diverged to NaN"
+
+    value = args.steps * n * world / elapsed
+    out = {
+        "metric": "climate-field samples/sec (G+D step) at 1152x768x16" if (h, w, c) == (1152, 768, 16)
+        else f"climate-field samples/sec (G+D step) at {h}x{w}x{c}",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{h}x{w}x{c} synthetic fields, batch {n}/GPU, DeepLabv3+/Xception-65 generator "
+                               "(Interpolate upsampler, noise_dimensions 0) + Xception-65/Linear discriminator, "
+                               "BatchNorm, ModifiedMinMax + L1, Adam(1e-4, eps 1e-8, wd 1e-5), D-step + G-step per step",
+                   "global_batch": n * world, "parallelism": f"dp{world}", "last_d_loss": d_loss, "last_g_loss": g_loss},
+    }
+
+    # ---- roofline: one extra (un-timed) step with HIP events around every C-ABI launch
+    if rank == 0 and not args.no_kernel_profile:
+        L.PROFILE = []
+        trainer.step(*batches[0])
+        torch.cuda.synchronize()
+        recs, L.PROFILE = L.PROFILE, None
+        fam = {}
+        for name, flops, e0, e1 in recs:
+            f = fam.setdefault(name, [0, 0.0, 0.0])
+            f[0] += 1
+            f[1] += e0.elapsed_time(e1) * 1e-3
+            f[2] += flops
+        mfma = {k: v for k, v in fam.items() if k.startswith("bg_conv2d")}
+        dom = max(mfma, key=lambda k: mfma[k][1])
+        cnt, secs, flops = mfma[dom]
+        achieved = flops / secs * 1e-12
+        walg = W_ALG_TFLOP.get((h, w, c))
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+            "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": None,
+            "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt, "alg_gflop_per_launch": flops / cnt * 1e-9,
+            "step_conv_stack_tflops": None if walg is None else value / world * walg,
+            "step_conv_stack_frac": None if walg is None else value / world * walg / PEAK_BF16_TFLOPS,
+            "families": {k: {"launches": v[0], "total_ms": 1e3 * v[1], "tflops": (v[2] / v[1] * 1e-12 if v[1] > 0 else 0.0)}
+                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(c, h, w)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,9 +111,27 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# When set to a list, every call is bracketed by HIP events recorded on the stream the
+# kernel is launched on (torch's current stream IS that stream): bench.py uses it for
+# the per-kernel durations of its roofline object.  None (default) = no overhead.
+PROFILE = None
+
+
+def _conv_flops(desc) -> float:
+    return 2.0 * desc.N * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.KH * desc.KW
+
+
 def call(name, *args):
     """Call an entry point on the current HIP stream; raise on a non-zero status."""
     lib = load()
-    rc = getattr(lib, name)(*args, stream())
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, stream())
+        e1.record()
+        flops = _conv_flops(args[0]) if name.startswith("bg_conv2d") else 0.0
+        PROFILE.append((name, flops, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.bg_last_error().decode()}")

@@ -9,9 +9,49 @@
 
 namespace {
 
+// ----------------------------------------------------------------- tiling ----
+// A [rows, C] activation is walked by 256-thread blocks shaped TX (channel
+// vectors, lanes along channels -> 16 B per lane, contiguous) x TY (rows).
+// grid: x = channel-vector blocks, y = row chunks inside a group, z = group.
+// No integer division anywhere on the per-element path.
+struct Tiling {
+    int tx, log_tx;      // channel vectors per block (power of two: 16, 32 or 64)
+    int gx;              // blocks along channels
+    int rows_per_block;  // rows walked by one block
+    int gy;
+};
+
+inline Tiling make_tiling(int dtype, int C, long long rows_per_group, int groups, int min_rows_per_thread,
+                          int target_blocks) {
+    const int cv = C / dtype_vec(dtype);
+    int best = 16, best_pad = 1 << 30;
+    for (int tx = 16; tx <= 64; tx *= 2) {
+        const int pad = (cv + tx - 1) / tx * tx;
+        if (pad <= best_pad) { best_pad = pad; best = tx; }
+    }
+    Tiling t;
+    t.tx = best;
+    t.log_tx = best == 16 ? 4 : (best == 32 ? 5 : 6);
+    t.gx = (cv + best - 1) / best;
+    const int ty = 256 / best;
+    long long want = target_blocks / ((long long)t.gx * groups);
+    if (want < 1) want = 1;
+    long long rpb = (rows_per_group + want - 1) / want;
+    const long long min_rpb = (long long)ty * min_rows_per_thread;
+    if (rpb < min_rpb) rpb = min_rpb;
+    if (rpb > (1 << 30)) rpb = 1 << 30;
+    t.rows_per_block = (int)rpb;
+    long long gy = (rows_per_group + rpb - 1) / rpb;
+    if (gy > 65535) {  // keep the grid legal for enormous inputs
+        gy = 65535;
+        t.rows_per_block = (int)((rows_per_group + gy - 1) / gy);
+        gy = (rows_per_group + t.rows_per_block - 1) / t.rows_per_block;
+    }
+    t.gy = (int)gy;
+    return t;
+}
+
 // ------------------------------------------------------------ column reduce --
-// block: 16 channel vectors (threadIdx.x & 15) x 16 row lanes (threadIdx.x >> 4)
-// grid : x = channel-vector blocks, y = row chunks inside a group, z = group
 enum { RED_STATS = 0, RED_BWD = 1, RED_COLSUM = 2 };
 
 struct RedParams {
@@ -25,6 +65,7 @@ struct RedParams {
     long long rows_per_group;
     int rows_per_block;
     int C;
+    int tx, log_tx;
     double* o1;
     double* o2;
     float* of;  // colsum output
@@ -34,9 +75,12 @@ struct RedParams {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
     constexpr int VEC = Elem<T>::VEC;
-    const int cvi = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int rlane = threadIdx.x >> 4;
-    const int c = cvi * VEC;
+    constexpr int NS = (MODE == RED_COLSUM) ? 1 : 2;
+    __shared__ float red[256 * VEC * NS];
+    const int lx = threadIdx.x & (P.tx - 1);
+    const int ly = threadIdx.x >> P.log_tx;
+    const int ty = 256 >> P.log_tx;
+    const int c = (blockIdx.x * P.tx + lx) * VEC;
     const bool c_ok = c < P.C;
     const int g = blockIdx.z;
     const long long r0 = (long long)blockIdx.y * P.rows_per_block;
@@ -56,13 +100,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
         }
     }
     if (c_ok) {
-        const T* a = reinterpret_cast<const T*>(P.a);
-        const T* b = reinterpret_cast<const T*>(P.b);
-        const T* cc = reinterpret_cast<const T*>(P.c);
-        for (long long r = r0 + rlane; r < r1; r += 16) {
-            const long long row = gbase + r;
+        const T* a = reinterpret_cast<const T*>(P.a) + (gbase + r0 + ly) * P.lda + c;
+        const T* b = reinterpret_cast<const T*>(P.b) + (gbase + r0 + ly) * P.ldb + c;
+        const T* cc = P.c ? reinterpret_cast<const T*>(P.c) + (gbase + r0 + ly) * P.ldc + c : nullptr;
+        const long long sa = (long long)ty * P.lda, sb = (long long)ty * P.ldb, sc = (long long)ty * P.ldc;
+#pragma unroll 4
+        for (long long r = r0 + ly; r < r1; r += ty) {
             Chunk<T> va;
-            va.load(a + row * P.lda + c);
+            va.load(a);
+            a += sa;
             if (MODE == RED_STATS) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
@@ -75,8 +121,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
                 for (int e = 0; e < VEC; ++e) s1[e] += va.get(e);
             } else {
                 Chunk<T> vy, vx;
-                if (P.act) vy.load(b + row * P.ldb + c);
-                if (cc) vx.load(cc + row * P.ldc + c);
+                if (P.act) { vy.load(b); b += sb; }
+                if (cc) { vx.load(cc); cc += sc; }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float gg = va.get(e);
@@ -87,46 +133,36 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
             }
         }
     }
+    // block reduction over the TY row lanes through LDS, then ONE atomic per (channel, statistic)
+    // layout: red[stat][ly][lx*VEC + e]
+    const int row_w = P.tx * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        float v = s1[e];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        s1[e] = v;
-        if (MODE != RED_COLSUM) {
-            float u = s2[e];
-            u += __shfl_xor(u, 16, 64);
-            u += __shfl_xor(u, 32, 64);
-            s2[e] = u;
-        }
+        red[(0 * ty + ly) * row_w + lx * VEC + e] = s1[e];
+        if (NS == 2) red[(1 * ty + ly) * row_w + lx * VEC + e] = s2[e];
     }
-    if (c_ok && (threadIdx.x & 63) < 16) {
-        const long long o = (long long)g * P.C + c;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            if (MODE == RED_COLSUM) {
-                atomicAdd(P.of + o + e, s1[e] * P.scale);
-            } else {
-                atomicAdd(P.o1 + o + e, (double)s1[e]);
-                if (P.o2) atomicAdd(P.o2 + o + e, (double)s2[e]);
-            }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NS * row_w; i += 256) {
+        const int st = i / row_w;  // 0 or 1 (uniform per 256-thread pass when row_w >= 256, cheap otherwise)
+        const int col = i - st * row_w;
+        float acc = 0.f;
+        for (int y = 0; y < ty; ++y) acc += red[(st * ty + y) * row_w + col];
+        const int ch = blockIdx.x * row_w + col;
+        if (ch < P.C) {
+            const long long o = (long long)g * P.C + ch;
+            if (MODE == RED_COLSUM) atomicAdd(P.of + o, acc * P.scale);
+            else if (st == 0) atomicAdd(P.o1 + o, (double)acc);
+            else if (P.o2) atomicAdd(P.o2 + o, (double)acc);
         }
     }
 }
 
 template <int MODE>
 int launch_colreduce(int dtype, RedParams P, int groups, hipStream_t st, const char* who) {
-    const int vec = dtype_vec(dtype);
-    const int gx = (P.C / vec + 15) / 16;
-    long long want = 4096 / ((long long)gx * groups);
-    if (want < 1) want = 1;
-    long long rpb = (P.rows_per_group + want - 1) / want;
-    if (rpb < 128) rpb = 128;
-    if (rpb > 1 << 20) rpb = 1 << 20;
-    P.rows_per_block = (int)rpb;
-    const long long gy = (P.rows_per_group + rpb - 1) / rpb;
-    BG_CHECK_ARG(gy <= 65535 && groups <= 65535, "%s: grid too large", who);
-    dim3 grid(gx, (unsigned)gy, (unsigned)groups);
+    const Tiling t = make_tiling(dtype, P.C, P.rows_per_group, groups, 16, 1536);
+    P.tx = t.tx; P.log_tx = t.log_tx; P.rows_per_block = t.rows_per_block;
+    BG_CHECK_ARG(groups <= 65535, "%s: too many groups", who);
+    dim3 grid(t.gx, t.gy, (unsigned)groups);
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, st, P));
     BG_CHECK_LAUNCH(who);
     return BG_OK;
@@ -204,34 +240,47 @@ struct EwParams {
     const float* scale; const float* shift;
     const void* res; int ldres;
     void* y; int ldy;
-    long long rows; int C; long long rows_per_group; int act;
+    int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
 };
 
 template <typename T>
-__global__ void norm_act_fwd_kernel(EwParams P) {
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     constexpr int VEC = Elem<T>::VEC;
-    const int cv = P.C / VEC;
-    const long long total = P.rows * cv;
-    const T* x = reinterpret_cast<const T*>(P.x);
-    const T* res = reinterpret_cast<const T*>(P.res);
-    T* y = reinterpret_cast<T*>(P.y);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * VEC;
-        const long long row = i / cv;
+    const int lx = threadIdx.x & (P.tx - 1);
+    const int ly = threadIdx.x >> P.log_tx;
+    const int ty = 256 >> P.log_tx;
+    const int c = (blockIdx.x * P.tx + lx) * VEC;
+    if (c >= P.C) return;
+    const int g = blockIdx.z;
+    const long long r0 = (long long)blockIdx.y * P.rows_per_block;
+    long long r1 = r0 + P.rows_per_block;
+    if (r1 > P.rows_per_group) r1 = P.rows_per_group;
+    const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = P.scale ? P.scale[(long long)g * P.C + c + e] : 1.f;
+        sh[e] = P.scale ? P.shift[(long long)g * P.C + c + e] : 0.f;
+    }
+    const T* x = reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c;
+    const T* res = P.res ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
+    T* y = reinterpret_cast<T*>(P.y) + row0 * P.ldy + c;
+    const long long sx = (long long)ty * P.ldx, sr = (long long)ty * P.ldres, sy = (long long)ty * P.ldy;
+#pragma unroll 4
+    for (long long r = r0 + ly; r < r1; r += ty) {
         Chunk<T> vx, vr, vo;
-        vx.load(x + row * P.ldx + c);
-        if (res) vr.load(res + row * P.ldres + c);
-        const long long so = (row / P.rows_per_group) * P.C + c;
+        vx.load(x);
+        x += sx;
+        if (res) { vr.load(res); res += sr; }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float z = vx.get(e);
-            if (P.scale) z = fmaf(z, P.scale[so + e], P.shift[so + e]);
+            float z = fmaf(vx.get(e), sc[e], sh[e]);
             if (res) z += vr.get(e);
             if (P.act) z = lrelu_f(z);
             vo.set(e, z);
         }
-        vo.store(y + row * P.ldy + c);
+        vo.store(y);
+        y += sy;
     }
 }
 
@@ -242,50 +291,66 @@ struct EwBwdParams {
     const float* A; const float* B; const float* Cc;
     void* dx; int lddx;
     void* dres; int lddres;
-    long long rows; int C; long long rows_per_group; int act;
+    int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
 };
 
 template <typename T>
-__global__ void norm_act_bwd_apply_kernel(EwBwdParams P) {
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) {
     constexpr int VEC = Elem<T>::VEC;
-    const int cv = P.C / VEC;
-    const long long total = P.rows * cv;
-    const T* dy = reinterpret_cast<const T*>(P.dy);
-    const T* y = reinterpret_cast<const T*>(P.y);
-    const T* x = reinterpret_cast<const T*>(P.x);
-    T* dx = reinterpret_cast<T*>(P.dx);
-    T* dres = reinterpret_cast<T*>(P.dres);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * VEC;
-        const long long row = i / cv;
+    const int lx = threadIdx.x & (P.tx - 1);
+    const int ly = threadIdx.x >> P.log_tx;
+    const int ty = 256 >> P.log_tx;
+    const int c = (blockIdx.x * P.tx + lx) * VEC;
+    if (c >= P.C) return;
+    const int g = blockIdx.z;
+    const long long r0 = (long long)blockIdx.y * P.rows_per_block;
+    long long r1 = r0 + P.rows_per_block;
+    if (r1 > P.rows_per_group) r1 = P.rows_per_group;
+    const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
+    const bool useB = P.A && P.B;
+    float ca[VEC], cb[VEC], cc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const long long so = (long long)g * P.C + c + e;
+        ca[e] = P.A ? P.A[so] : 1.f;
+        cb[e] = useB ? P.B[so] : 0.f;
+        cc[e] = useB ? P.Cc[so] : 0.f;
+    }
+    const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;
+    const T* y = P.act ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
+    const T* x = useB ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
+    T* dx = P.dx ? reinterpret_cast<T*>(P.dx) + row0 * P.lddx + c : nullptr;
+    T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + row0 * P.lddres + c : nullptr;
+    const long long s_dy = (long long)ty * P.lddy, s_y = (long long)ty * P.ldy, s_x = (long long)ty * P.ldx;
+    const long long s_dx = (long long)ty * P.lddx, s_dr = (long long)ty * P.lddres;
+#pragma unroll 4
+    for (long long r = r0 + ly; r < r1; r += ty) {
         Chunk<T> vg, vy, vx, vo;
-        vg.load(dy + row * P.lddy + c);
-        if (P.act) vy.load(y + row * P.ldy + c);
-        if (P.A && P.B) vx.load(x + row * P.ldx + c);
-        const long long so = (row / P.rows_per_group) * P.C + c;
-        float g[VEC];
+        vg.load(dy);
+        dy += s_dy;
+        if (y) { vy.load(y); y += s_y; }
+        if (x) { vx.load(x); x += s_x; }
+        float gg[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            g[e] = vg.get(e);
-            if (P.act) g[e] *= (vy.get(e) > 0.f ? 1.f : LRELU_SLOPE);
+            gg[e] = vg.get(e);
+            if (P.act) gg[e] *= (vy.get(e) > 0.f ? 1.f : LRELU_SLOPE);
         }
         if (dres) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) vo.set(e, g[e]);
-            vo.store(dres + row * P.lddres + c);
+            for (int e = 0; e < VEC; ++e) vo.set(e, gg[e]);
+            vo.store(dres);
+            dres += s_dr;
         }
         if (dx) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float d = g[e];
-                if (P.A) {
-                    d *= P.A[so + e];
-                    if (P.B) d += fmaf(P.B[so + e], vx.get(e), P.Cc[so + e]);
-                }
+                float d = gg[e] * ca[e];
+                if (useB) d += fmaf(cb[e], vx.get(e), cc[e]);
                 vo.set(e, d);
             }
-            vo.store(dx + row * P.lddx + c);
+            vo.store(dx);
+            dx += s_dx;
         }
     }
 }
@@ -402,9 +467,10 @@ extern "C" int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const 
         BG_CHECK_ARG(aligned16(res), "bg_norm_act_fwd: unaligned res");
         CHECK_LD(ldres, "bg_norm_act_fwd");
     }
-    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, rows, C, rows / groups, act};
-    const long long total = rows * (C / dtype_vec(dtype));
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
+    BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd: too many groups");
+    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx};
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_fwd_kernel");
     return BG_OK;
@@ -435,9 +501,11 @@ extern "C" int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy
         BG_CHECK_ARG(aligned16(dres), "bg_norm_act_bwd_apply: unaligned dres");
         CHECK_LD(lddres, "bg_norm_act_bwd_apply");
     }
-    EwBwdParams P{dy, lddy, y, ldy, x, ldx, A, B, Cc, dx, lddx, dres, lddres, rows, C, rows / groups, act};
-    const long long total = rows * (C / dtype_vec(dtype));
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
+    BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply: too many groups");
+    EwBwdParams P{dy, lddy, y, ldy, x, ldx, A, B, Cc, dx, lddx, dres, lddres, C, rows / groups, t.rows_per_block, act,
+                  t.tx, t.log_tx};
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel");
     return BG_OK;

@@ -138,24 +138,27 @@ class Conv2dFn(torch.autograd.Function):
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), kp)
         L.call("bg_conv2d_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot),
                None if bslot is None else arena.master_ptr(bslot), y.data_ptr())
-        ctx.save_for_backward(x)
-        ctx.meta = (arena, wslot, bslot, stride, pad, dil, ho, wo)
+        # the input is only needed for the weight gradient: do not keep it alive otherwise
+        # (G-step: the discriminator is differentiated w.r.t. its input only)
+        if weight.requires_grad:
+            ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, bslot, stride, pad, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        arena, wslot, bslot, stride, pad, dil, ho, wo = ctx.meta
+        arena, wslot, bslot, stride, pad, dil, ho, wo, xshape, xdtype, xdev = ctx.meta
         g = nhwc(g)
-        n, h, w, cin = x.shape
+        n, h, w, cin = xshape
         kp, kh, kw, cp = wslot.phys_shape
-        desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(g))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = new_act(n, h, w, cin, x.dtype, x.device)
-            d2 = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, cin, ld_of(g))
+            dx = new_act(n, h, w, cin, xdtype, xdev)
+            d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, cin, ld_of(g))
             L.call("bg_conv2d_bwd_data", d2, g.data_ptr(), arena.weight_t_ptr(wslot), dx.data_ptr())
         if ctx.needs_input_grad[1]:
+            (x,) = ctx.saved_tensors
+            desc = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(g))
             arena.ensure_grad(wslot)
             dbias = None
             if bslot is not None and ctx.needs_input_grad[2]:
@@ -177,24 +180,25 @@ class DwConv3x3Fn(torch.autograd.Function):
         y = new_act(n, ho, wo, c, x.dtype, x.device)
         desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), c)
         L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
-        ctx.save_for_backward(x)
-        ctx.meta = (arena, wslot, stride, dil, ho, wo)
+        if weight.requires_grad:
+            ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, stride, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        arena, wslot, stride, dil, ho, wo = ctx.meta
+        arena, wslot, stride, dil, ho, wo, xshape, xdtype, xdev = ctx.meta
         g = nhwc(g)
-        n, h, w, c = x.shape
+        n, h, w, c = xshape
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = new_act(n, h, w, c, x.dtype, x.device)
-            desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, c, ld_of(g))
+            dx = new_act(n, h, w, c, xdtype, xdev)
+            desc = L.DwDesc(L.dt(xdtype), n, h, w, c, ho, wo, stride, dil, c, ld_of(g))
             L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), dx.data_ptr())
         if ctx.needs_input_grad[1]:
+            (x,) = ctx.saved_tensors
             arena.ensure_grad(wslot)
-            desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(g))
+            desc = L.DwDesc(L.dt(xdtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(g))
             L.call("bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
         return dx, None, None, None, None, None
 
