@@ -1,0 +1,154 @@
+"""CPU-only tests of the host logic: module/state_dict mirror, host RNG label
+draws, optimiser/schedule plumbing, and the N>1 path (world_size 2 over gloo)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+import bias_gan_amd  # noqa: F401
+from bias_gan_amd.architecture.gpsro import deeplab as dl
+from bias_gan_amd.architecture.gpsro import deeplab_gan as dxg
+from bias_gan_amd.comm.distributed import FlatAllReduce, comm
+from bias_gan_amd.utils import losses
+from bias_gan_amd.utils import parsing_helpers as ph
+
+
+def test_state_dict_keys_match_reference(golden_dir, capsys):
+    ref = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    G = dxg.Generator(16, 16, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d)
+    D = dxg.Discriminator(16, normalizer=nn.BatchNorm2d, input_size=(64, 64))
+    assert [[k, list(v.shape)] for k, v in G.state_dict().items()] == ref["generator_c16"]
+    assert [[k, list(v.shape)] for k, v in D.state_dict().items()] == ref["discriminator_c16_64x64"]
+    # the reference's default head (19x37 grid) is 12288 wide (deeplab_gan.py:21)
+    assert dxg.Discriminator(4, normalizer=nn.BatchNorm2d).linear.in_features == 12288
+    # InstanceNorm contributes no entries (defaults: no affine, no running stats)
+    Di = dxg.Discriminator(4, normalizer=nn.InstanceNorm2d, input_size=(64, 64))
+    assert all("running" not in k for k in Di.state_dict())
+
+
+def test_init_distributions_follow_reference():
+    torch.manual_seed(0)
+    D = dxg.Discriminator(16, normalizer=nn.BatchNorm2d, input_size=(64, 64))
+    w = D.xception_features.block5.rep[1].pointwise.weight  # 728 -> 728, k=1
+    gain = nn.init.calculate_gain("leaky_relu", 0.2)
+    assert abs(w.std().item() - gain / np.sqrt(728)) < 0.05 * gain / np.sqrt(728)   # deeplab_gan.py:46-52
+    assert float(D.linear.bias.abs().sum()) == 0.0
+    G = dxg.Generator(16, 16, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d)
+    w = G.model.xception_features.block5.rep[1].pointwise.weight
+    assert abs(w.std().item() - np.sqrt(2.0 / 728)) < 0.05 * np.sqrt(2.0 / 728)    # kaiming_normal_, deeplab.py:285
+
+
+def test_no_cpu_fallback():
+    G = dxg.Generator(4, 4, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G(torch.zeros(2, 4, 64, 64))
+    with pytest.raises(NotImplementedError):
+        dxg.Generator(4, 4, "Deconv1x", "Uniform", 0, normalizer=nn.BatchNorm2d)
+    with pytest.raises(NotImplementedError):
+        dxg.Generator(4, 4, "Interpolate", "Cauchy", 0)
+
+
+def test_block_unit_layout():
+    b = dl.Block(128, 128, reps=2, stride=2, start_with_relu=False, normalizer=nn.BatchNorm2d)
+    kinds = [type(m).__name__ for m in b.rep]
+    assert kinds == ["SeparableConv2d_same", "BatchNorm2d", "LeakyReLU", "SeparableConv2d_same", "BatchNorm2d",
+                     "SeparableConv2d_same"]
+    assert b.skip is not None and dl.fixed_padding_extents(3, 2) == (2, 2) and dl.fixed_padding_extents(3, 1) == (1, 1)
+
+
+def test_ganloss_host_draws_bit_exact(golden_dir):
+    z = np.load(os.path.join(golden_dir, "losses.npz"))
+    crit = losses.GANLoss("ModifiedMinMax", 4, torch.device("cpu"))
+    for seed in (0, 7, 123, 999):
+        torch.manual_seed(seed)
+        lf, lr, swap = crit.draw_labels()
+        np.testing.assert_array_equal(lf.numpy(), z[f"ModifiedMinMax_{seed}::label_fake"])
+        np.testing.assert_array_equal(lr.numpy(), z[f"ModifiedMinMax_{seed}::label_real"])
+        assert swap == bool(z[f"ModifiedMinMax_{seed}::swap_u"] < 0.05)
+    with pytest.raises(NotImplementedError):
+        losses.GANLoss("Hinge", 4, torch.device("cpu"))
+
+
+def test_optimizer_factory_and_schedules():
+    p = [nn.Parameter(torch.zeros(3))]
+    opt = ph.get_optimizer(p, "Adam", 1e-3, 1e-8, 1e-4)
+    assert opt.param_groups[0]["initial_lr"] == 1e-3 and not opt.param_groups[0]["decoupled"]
+    assert ph.get_optimizer(p, "AdamW", 1e-3, 1e-8, 1e-4).param_groups[0]["decoupled"]
+    with pytest.raises(NotImplementedError):
+        ph.get_optimizer(p, "LAMB", 1e-3, 1e-8, 1e-4)
+    sch = ph.get_lr_schedule(1e-3, {"type": "multistep", "milestones": "2 4", "decay_rate": "0.1"}, opt)
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]["lr"])
+        sch.step()
+    assert np.allclose(lrs, [1e-3, 1e-3, 1e-4, 1e-4, 1e-5])
+    ph.get_lr_schedule(1e-3, {"type": "cosine_annealing", "t_max": 10, "eta_min": 0.0}, opt)
+    with pytest.raises(ValueError):
+        ph.get_lr_schedule(1e-3, {"type": "nope"}, opt)
+    with pytest.raises(RuntimeError, match="not in an arena"):
+        opt.step()   # parameters that never went through a GPU forward
+
+
+def test_comm_dummy_single_process():
+    c = comm(mode="dummy")
+    assert c.size() == 1 and c.rank() == 0 and c.local_rank() == 0
+    assert c.metric_average(torch.tensor(2.5), "x") == 2.5 and c.metric_average(3, "x") == 3
+    m = nn.Linear(2, 2)
+    assert c.DistributedModel(m) is m and c.DistributedOptimizer("o", None, None, "average") == "o"
+    assert c.init_gan_training_state(None, None, None, None, None, "cpu") == (0, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    c = comm(mode="torchrun")                    # picks gloo on a CPU-only box
+    assert c.size() == world and c.rank() == rank
+    # metric_average: SUM by default, mean with op_name="average" (comm/distributed.py:15-17)
+    s = c.metric_average(torch.tensor(float(rank + 1)), "loss")
+    a = c.metric_average(torch.tensor(float(rank + 1)), "loss", op_name="average")
+    # flat gradient all-reduce in several buckets, asynchronous launch then finish
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    far = FlatAllReduce(flat, bucket_elems=300)
+    assert len(far.buckets()) == 4
+    far.launch()
+    far.finish()
+    far2 = FlatAllReduce(torch.ones(7) * (rank + 1))
+    far2.finish()                                # finish() alone also launches
+    t = torch.full((3,), float(rank))
+    c.broadcast(t, 0)
+    # dataset-style sharding contract of the reference (gpsro_dataset.py:24-33): contiguous slices of one shuffle
+    q.put((rank, s, a, flat.sum().item(), far2.flat.tolist(), t.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, s, a, fsum, f2, t in res:
+        assert s == 3.0 and a == 1.5
+        assert fsum == float(np.arange(1000).sum() * 3)
+        assert f2 == [3.0] * 7
+        assert t == [0.0, 0.0, 0.0]
