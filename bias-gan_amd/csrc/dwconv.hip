@@ -52,6 +52,65 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwParams P) {
     o.store(reinterpret_cast<T*>(P.y) + (((long long)n * P.Ho + ho) * P.Wo + wo) * P.ldy + c);
 }
 
+// Register-blocked variant: one thread produces TW = 4 consecutive output pixels of
+// a row for one channel vector and loads every input column it needs ONCE
+// (stride 1, dilation 1: 18 loads for 4 outputs instead of 36).  FLIP = 1 applies the
+// taps reversed, which for stride 1 is exactly the data gradient (dy in, dx out).
+template <typename T, int S, int D, int FLIP>
+__global__ __launch_bounds__(256) void dw_fwd_tw_kernel(DwParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int TW = 4;
+    constexpr int NCOL = (TW - 1) * S + 2 * D + 1;
+    const unsigned cv = P.C / VEC;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)P.items) return;
+    const unsigned wq = idx / cv;
+    const int c = (int)(idx - wq * cv) * VEC;
+    const int wo0 = (int)wq * TW;
+    const int n = blockIdx.y / P.Ho, ho = blockIdx.y - n * P.Ho;
+    const T* x = reinterpret_cast<const T*>(P.x) + (long long)n * P.H * P.W * P.ldx + c;
+    const T* w = reinterpret_cast<const T*>(P.w) + c;
+    float acc[TW][VEC];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    const int iw0 = wo0 * S - D;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int ih = ho * S - D + r * D;
+        if ((unsigned)ih >= (unsigned)P.H) continue;
+        Chunk<T> wv[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wv[s].load(w + ((FLIP ? (2 - r) : r) * 3 + (FLIP ? (2 - s) : s)) * P.C);
+        const T* xr = x + (long long)ih * P.W * P.ldx;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            const int iw = iw0 + j;
+            if ((unsigned)iw >= (unsigned)P.W) continue;
+            Chunk<T> xv;
+            xv.load(xr + (long long)iw * P.ldx);
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (j == t * S + s * D) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[t][e] = fmaf(xv.get(e), wv[s].get(e), acc[t][e]);
+                    }
+        }
+    }
+    T* y = reinterpret_cast<T*>(P.y) + (((long long)n * P.Ho + ho) * P.Wo + wo0) * P.ldy + c;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        if (wo0 + t >= P.Wo) break;
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, acc[t][e]);
+        o.store(y + (long long)t * P.ldy);
+    }
+}
+
 // dx[n,h,w,c] = sum_{r,s} dy[n,ho,wo,c] * w[r,s,c]  with ho*stride - dil + r*dil == h
 template <typename T>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwParams P) {
@@ -106,7 +165,7 @@ struct DwWParams {
     int tx, log_tx;
 };
 
-template <typename T>
+template <typename T, int FAST /* stride 1, dilation 1: sliding 3-column window */>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwWParams P) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[256 * VEC];
@@ -125,7 +184,47 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwWParams P) {
     const int row0 = blockIdx.y * P.rows_per_block;
     int row1 = row0 + P.rows_per_block;
     if (row1 > P.rows_total) row1 = P.rows_total;
-    if (c_ok) {
+    if (c_ok && FAST) {
+        // each row lane walks a contiguous strip of the output row and keeps the three
+        // input columns of its stencil in registers: 3 new loads per output instead of 9
+        const int strip = (P.Wo + ty - 1) / ty;
+        const int w_begin = ly * strip;
+        int w_end = w_begin + strip;
+        if (w_end > P.Wo) w_end = P.Wo;
+        for (int row = row0; row < row1 && w_begin < w_end; ++row) {
+            const int n = row / P.Ho, ho = row - n * P.Ho;
+            const T* dyr = dy + (long long)row * P.Wo * P.ldy;
+            const T* xn = x + (long long)n * P.H * P.W * P.ldx;
+            Chunk<T> c0[3], c1[3], c2[3];
+            bool rok[3];
+            const T* xr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int ih = ho - 1 + r;
+                rok[r] = (unsigned)ih < (unsigned)P.H;
+                xr[r] = xn + (long long)(rok[r] ? ih : 0) * P.W * P.ldx;
+                if (rok[r] && w_begin - 1 >= 0) c0[r].load(xr[r] + (long long)(w_begin - 1) * P.ldx); else c0[r].zero();
+                if (rok[r]) c1[r].load(xr[r] + (long long)w_begin * P.ldx); else c1[r].zero();
+            }
+            for (int wo = w_begin; wo < w_end; ++wo) {
+                Chunk<T> gv;
+                gv.load(dyr + (long long)wo * P.ldy);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (rok[r] && wo + 1 < P.W) c2[r].load(xr[r] + (long long)(wo + 1) * P.ldx); else c2[r].zero();
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float g = gv.get(e);
+                        acc[r * 3 + 0][e] = fmaf(g, c0[r].get(e), acc[r * 3 + 0][e]);
+                        acc[r * 3 + 1][e] = fmaf(g, c1[r].get(e), acc[r * 3 + 1][e]);
+                        acc[r * 3 + 2][e] = fmaf(g, c2[r].get(e), acc[r * 3 + 2][e]);
+                    }
+                    c0[r] = c1[r];
+                    c1[r] = c2[r];
+                }
+            }
+        }
+    } else if (c_ok) {
         for (int row = row0; row < row1; ++row) {
             const int n = row / P.Ho, ho = row - n * P.Ho;  // wave-uniform
             const T* dyr = dy + (long long)row * P.Wo * P.ldy;
@@ -187,12 +286,22 @@ extern "C" int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const vo
     if (rc) return rc;
     BG_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "bg_dwconv3x3_fwd: null/unaligned pointer");
     DwParams P{x, w, y, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0};
-    P.items = d->Wo * (d->C / dtype_vec(d->dtype));
     const long long rows = (long long)d->N * d->Ho;
     BG_CHECK_ARG(rows <= 65535, "bg_dwconv3x3_fwd: N*Ho too large");
-    dim3 grid((P.items + 255) / 256, (unsigned)rows);
     hipStream_t st = (hipStream_t)stream;
-    BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_kernel<T>), grid, dim3(256), 0, st, P));
+    const int cv = d->C / dtype_vec(d->dtype);
+    const int sd = d->stride * 10 + d->dil;
+    if (sd == 11 || sd == 12 || sd == 21) {
+        P.items = ((d->Wo + 3) / 4) * cv;
+        dim3 grid((P.items + 255) / 256, (unsigned)rows);
+        if (sd == 11) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 1, 0>), grid, dim3(256), 0, st, P));
+        else if (sd == 12) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 2, 0>), grid, dim3(256), 0, st, P));
+        else BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 2, 1, 0>), grid, dim3(256), 0, st, P));
+    } else {
+        P.items = d->Wo * cv;
+        dim3 grid((P.items + 255) / 256, (unsigned)rows);
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_kernel<T>), grid, dim3(256), 0, st, P));
+    }
     BG_CHECK_LAUNCH("dw_fwd_kernel");
     return BG_OK;
 }
@@ -203,11 +312,23 @@ extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, co
     BG_CHECK_ARG(dy && w && dx && aligned16(dy) && aligned16(w) && aligned16(dx),
                  "bg_dwconv3x3_bwd_data: null/unaligned pointer");
     DwParams P{dy, w, dx, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0};
-    P.items = d->W * (d->C / dtype_vec(d->dtype));
     const long long rows = (long long)d->N * d->H;
     BG_CHECK_ARG(rows <= 65535, "bg_dwconv3x3_bwd_data: N*H too large");
-    dim3 grid((P.items + 255) / 256, (unsigned)rows);
     hipStream_t st = (hipStream_t)stream;
+    const int cv = d->C / dtype_vec(d->dtype);
+    if (d->stride == 1 && (d->dil == 1 || d->dil == 2)) {
+        // stride 1: the data gradient is the same stencil with the taps reversed
+        // (dy plays the input, dx the output; both are H x W)
+        DwParams Q{dy, w, dx, d->N, d->H, d->W, d->C, d->H, d->W, 1, d->dil, d->ldy, d->ldx, 0};
+        Q.items = ((d->W + 3) / 4) * cv;
+        dim3 grid((Q.items + 255) / 256, (unsigned)rows);
+        if (d->dil == 1) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 1, 1>), grid, dim3(256), 0, st, Q));
+        else BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 2, 1>), grid, dim3(256), 0, st, Q));
+        BG_CHECK_LAUNCH("dw_fwd_tw_kernel(flip)");
+        return BG_OK;
+    }
+    P.items = d->W * cv;
+    dim3 grid((P.items + 255) / 256, (unsigned)rows);
     BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_bwd_data_kernel<T>), grid, dim3(256), 0, st, P));
     BG_CHECK_LAUNCH("dw_bwd_data_kernel");
     return BG_OK;
@@ -236,8 +357,12 @@ extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, c
     P.rows_per_block = (P.rows_total + gy - 1) / gy;
     gy = (P.rows_total + P.rows_per_block - 1) / P.rows_per_block;
     hipStream_t st = (hipStream_t)stream;
-    BG_DISPATCH_DTYPE(d->dtype, T,
-                      hipLaunchKernelGGL((dw_bwd_weight_kernel<T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, P));
+    if (d->stride == 1 && d->dil == 1)
+        BG_DISPATCH_DTYPE(d->dtype, T,
+                          hipLaunchKernelGGL((dw_bwd_weight_kernel<T, 1>), dim3(gx, (unsigned)gy), dim3(256), 0, st, P));
+    else
+        BG_DISPATCH_DTYPE(d->dtype, T,
+                          hipLaunchKernelGGL((dw_bwd_weight_kernel<T, 0>), dim3(gx, (unsigned)gy), dim3(256), 0, st, P));
     BG_CHECK_LAUNCH("dw_bwd_weight_kernel");
     return BG_OK;
 }

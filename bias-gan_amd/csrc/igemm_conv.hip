@@ -25,6 +25,7 @@
 // dtype BG_F32 runs the same kernels on the f32-input MFMA (16x16x4 / 32x32x2):
 // exact fp32 products and accumulation, used as the parity path.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -129,21 +130,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
     const int row0 = tid / CPR;
     const int RS = P.KH * P.KW;
 
-    // per-thread row bookkeeping (fixed for the whole K loop)
+    // per-thread row bookkeeping (fixed for the whole K loop).  The gather address of
+    // a row for tap (r,s) is  row_off + tap_delta(r,s) + c  with a wave-uniform
+    // tap_delta, so the K loop does one 64-bit add and two compares per row.
+    long long pix_off[NPASS];  // element offset of the tap-(0,0) source pixel (may be "negative" = outside)
     long long pix_noff[NPASS];
     int pix_h[NPASS], pix_w[NPASS];
     bool pix_ok[NPASS];
     long long w_roff[NPASS];
     bool w_ok[NPASS];
+    const bool unit_stride_t = P.transposed && P.stride == 1;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const long long p = p_base + row0 + i * RPP;
         pix_ok[i] = p < P.M;
-        const long long pp = pix_ok[i] ? p : 0;
-        const int ohw = P.OH * P.OW;
-        const int n = (int)(pp / ohw);
-        const int rem = (int)(pp - (long long)n * ohw);
-        const int oh = rem / P.OW, ow = rem - oh * P.OW;
+        const unsigned pp = pix_ok[i] ? (unsigned)p : 0u;  // M < 2^31 (checked on the host)
+        const unsigned ohw = (unsigned)(P.OH * P.OW);
+        const unsigned n = pp / ohw;
+        const unsigned rem = pp - n * ohw;
+        const int oh = (int)(rem / (unsigned)P.OW), ow = (int)(rem - (rem / (unsigned)P.OW) * (unsigned)P.OW);
         pix_noff[i] = (long long)n * P.IH * P.IW;
         if (!P.transposed) {
             pix_h[i] = oh * P.stride - P.pad;
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
             pix_h[i] = oh + P.pad;
             pix_w[i] = ow + P.pad;
         }
+        pix_off[i] = (pix_noff[i] + (long long)pix_h[i] * P.IW + pix_w[i]) * P.ldi;
         const int co = c_base + row0 + i * RPP;
         w_ok[i] = co < P.NO;
         w_roff[i] = (long long)(w_ok[i] ? co : 0) * RS * P.CK;
@@ -176,21 +182,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
             if (w_ok[i] && c_ok) ra[i].load(wt + w_roff[i] + (long long)tap * P.CK + c);
             else ra[i].zero();
             // pixels (B operand)
-            int ih, iw;
             bool ok = pix_ok[i] && c_ok;
-            if (!P.transposed) {
-                ih = pix_h[i] + r * P.dil;
-                iw = pix_w[i] + s * P.dil;
+            if (!P.transposed || unit_stride_t) {
+                const int dh = P.transposed ? -r * P.dil : r * P.dil, dw_ = P.transposed ? -s * P.dil : s * P.dil;
+                const int ih = pix_h[i] + dh, iw = pix_w[i] + dw_;
                 ok = ok && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
+                const long long tap_delta = ((long long)dh * P.IW + dw_) * P.ldi;  // wave-uniform
+                if (ok) rb[i].load(in + pix_off[i] + tap_delta + c);
+                else rb[i].zero();
             } else {
                 const int th = pix_h[i] - r * P.dil, tw = pix_w[i] - s * P.dil;
                 ok = ok && th >= 0 && tw >= 0;
-                ih = th / P.stride;
-                iw = tw / P.stride;
+                const int ih = th / P.stride, iw = tw / P.stride;
                 ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
+                if (ok) rb[i].load(in + (pix_noff[i] + (long long)ih * P.IW + iw) * P.ldi + c);
+                else rb[i].zero();
             }
-            if (ok) rb[i].load(in + (pix_noff[i] + (long long)ih * P.IW + iw) * P.ldi + c);
-            else rb[i].zero();
         }
     };
     auto write_lds = [&](int buf) {
@@ -253,6 +260,174 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
             } else {
                 *reinterpret_cast<f32x4*>(dst) = v;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------- LDS-DMA forward/dgrad ----
+// Same tile, swizzle, MFMA schedule and epilogue as gemm_conv_kernel, but the
+// operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+// instruction) into a ring of NBUF stages, two K-steps ahead of the MFMAs:
+//   * no staging VGPRs, no ds_write pass;
+//   * one raw s_barrier per K-step, loads stay in flight across it and are retired
+//     with a COUNTED s_waitcnt vmcnt (never 0 inside the loop);
+//   * the LDS image of a DMA is lane-linear, so the XOR swizzle is applied to the
+//     SOURCE chunk each lane fetches (and to the fragment reads, as before);
+//   * rows that fall into padding / beyond the tensor fetch from a 16-byte zero
+//     constant instead (LDS-DMA cannot predicate a lane's write).
+__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BKB, int NBUF>
+__global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams P) {
+    typedef bf16_t T;
+    constexpr int VEC = 8;
+    constexpr int BK = BKB / 2;
+    constexpr int CPR = BKB / 16;   // chunks per row
+    constexpr int RPG = 64 / CPR;   // tile rows covered by one wave-wide DMA (1 KiB)
+    constexpr int NG = 32 / RPG;    // DMAs per operand per wave per K-step (a wave stages 32 rows)
+    constexpr int GROUP = 2 * NG;   // VMEM ops per wave per K-step
+    constexpr int TILE_BYTES = TILE * BKB;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int DIST = NBUF - 1;  // K-steps in flight ahead of the MFMAs
+    static_assert(DIST == 2, "the counted waits below assume two K-steps of prefetch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_c = wave >> 1, wave_p = wave & 1;
+
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
+    const long long p_base = (long long)tile_p * TILE;
+    const int c_base = tile_c * TILE;
+    const int RS = P.KH * P.KW;
+
+    const int lr = lane / CPR, lc = lane % CPR;
+    const T* in = reinterpret_cast<const T*>(P.in);
+    const T* wt = reinterpret_cast<const T*>(P.w);
+    const T* zsrc = reinterpret_cast<const T*>(g_zero16);
+
+    long long pix_off[NG], pix_noff[NG], w_roff[NG];
+    int pix_h[NG], pix_w[NG], chk[NG];
+    bool pix_ok[NG], w_ok[NG];
+    const bool unit_stride_t = P.transposed && P.stride == 1;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int row = wave * 32 + g * RPG + lr;  // row inside the 128-row tile (same for A and B)
+        chk[g] = (BKB == 64) ? (lc ^ ((0 - (row >> 2)) & 3)) : (lc ^ ((row >> 1) & 7));
+        const long long p = p_base + row;
+        pix_ok[g] = p < P.M;
+        const unsigned pp = pix_ok[g] ? (unsigned)p : 0u;
+        const unsigned ohw = (unsigned)(P.OH * P.OW);
+        const unsigned n = pp / ohw;
+        const unsigned rem = pp - n * ohw;
+        const unsigned q = rem / (unsigned)P.OW;
+        const int oh = (int)q, ow = (int)(rem - q * (unsigned)P.OW);
+        pix_noff[g] = (long long)n * P.IH * P.IW;
+        if (!P.transposed) {
+            pix_h[g] = oh * P.stride - P.pad;
+            pix_w[g] = ow * P.stride - P.pad;
+        } else {
+            pix_h[g] = oh + P.pad;
+            pix_w[g] = ow + P.pad;
+        }
+        pix_off[g] = (pix_noff[g] + (long long)pix_h[g] * P.IW + pix_w[g]) * P.ldi;
+        const int co = c_base + row;
+        w_ok[g] = co < P.NO;
+        w_roff[g] = (long long)(w_ok[g] ? co : 0) * RS * P.CK;
+    }
+
+    const int ksteps_per_tap = (P.CK + BK - 1) / BK;
+    const int KT = RS * ksteps_per_tap;
+
+    auto issue = [&](int kt, int buf) {
+        const int tap = kt / ksteps_per_tap;
+        const int c0 = (kt - tap * ksteps_per_tap) * BK;
+        const int r = tap / P.KW, s = tap - r * P.KW;
+        char* stage = smem + buf * STAGE_BYTES + wave * 32 * BKB;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int c = c0 + chk[g] * VEC;
+            const bool c_ok = c < P.CK;
+            const T* srcA = (w_ok[g] && c_ok) ? wt + w_roff[g] + (long long)tap * P.CK + c : zsrc;
+            __builtin_amdgcn_global_load_lds((glb_ptr)srcA, (lds_ptr)(stage + g * RPG * BKB), 16, 0, 0);
+            bool ok = pix_ok[g] && c_ok;
+            const T* srcB;
+            if (!P.transposed || unit_stride_t) {
+                const int dh = P.transposed ? -r * P.dil : r * P.dil, dw_ = P.transposed ? -s * P.dil : s * P.dil;
+                const int ih = pix_h[g] + dh, iw = pix_w[g] + dw_;
+                ok = ok && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
+                srcB = in + pix_off[g] + ((long long)dh * P.IW + dw_) * P.ldi + c;
+            } else {
+                const int th = pix_h[g] - r * P.dil, tw = pix_w[g] - s * P.dil;
+                ok = ok && th >= 0 && tw >= 0;
+                const int ih = th / P.stride, iw = tw / P.stride;
+                ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
+                srcB = in + (pix_noff[g] + (long long)ih * P.IW + iw) * P.ldi + c;
+            }
+            if (!ok) srcB = zsrc;
+            __builtin_amdgcn_global_load_lds((glb_ptr)srcB, (lds_ptr)(stage + TILE_BYTES + g * RPG * BKB), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    int buf = 0, nbuf = DIST % NBUF;
+    for (int kt = 0; kt < KT; ++kt) {
+        // retire this wave's DMAs of step kt (leave step kt+1's in flight), then meet the others
+        if (kt + 1 < KT) wait_vmcnt<GROUP>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        // stage (kt+2): its ring slot was last read in iteration kt-1, which every wave has left
+        if (kt + DIST < KT) issue(kt + DIST, nbuf);
+        const char* sA = smem + buf * STAGE_BYTES;
+        mma_slab<T, BKB>(sA, sA + TILE_BYTES, wave_c, wave_p, lane, acc);
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+        nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
+    }
+
+    T* out = reinterpret_cast<T*>(P.out);
+    const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = p_base + wave_p * 64 + j * 16 + r16;
+        if (p >= P.M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
+            if (co >= P.NO) continue;
+            f32x4 v = acc[i][j];
+            if (P.bias) {
+                v[0] += P.bias[co + 0];
+                v[1] += P.bias[co + 1];
+                v[2] += P.bias[co + 2];
+                v[3] += P.bias[co + 3];
+            }
+            bf16x4 o;
+            o[0] = (bf16_t)v[0];
+            o[1] = (bf16_t)v[1];
+            o[2] = (bf16_t)v[2];
+            o[3] = (bf16_t)v[3];
+            *reinterpret_cast<bf16x4*>(out + p * P.ldo + co) = o;
         }
     }
 }
@@ -363,6 +538,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     const T* x = reinterpret_cast<const T*>(P.x);
     const T* dy = reinterpret_cast<const T*>(P.dy);
     const int ohw = P.Ho * P.Wo;
+    const bool pointwise = RS == 1 && P.stride == 1 && P.pad == 0;
 
     Chunk<T> ra[NPASS], rb[NPASS];
     auto issue_loads = [&](long long pc) {
@@ -375,13 +551,18 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
             bool ok = pv && ci_ok;
             long long off = 0;
             if (ok) {
-                const int n = (int)(p / ohw);
-                const int rem = (int)(p - (long long)n * ohw);
-                const int oh = rem / P.Wo, ow = rem - oh * P.Wo;
-                const int ih = oh * P.stride - P.pad + r * P.dil;
-                const int iw = ow * P.stride - P.pad + s * P.dil;
-                ok = (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W;
-                off = (((long long)n * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC;
+                if (pointwise) {  // 1x1, stride 1, no padding: input pixel == output pixel
+                    off = p * P.ldx + ci_base + chunk * VEC;
+                } else {
+                    const unsigned pu = (unsigned)p;  // M < 2^31 (checked on the host)
+                    const unsigned n = pu / (unsigned)ohw;
+                    const unsigned rem = pu - n * (unsigned)ohw;
+                    const int oh = (int)(rem / (unsigned)P.Wo), ow = (int)(rem - (rem / (unsigned)P.Wo) * (unsigned)P.Wo);
+                    const int ih = oh * P.stride - P.pad + r * P.dil;
+                    const int iw = ow * P.stride - P.pad + s * P.dil;
+                    ok = (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W;
+                    off = (((long long)n * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC;
+                }
             }
             if (ok) rb[i].load(x + off);
             else rb[i].zero();
@@ -490,7 +671,26 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     // reduction depth is smaller with 64-byte rows (e.g. Cin = 728 -> 736 vs 768).
     const int bk64 = 64 / (int)sizeof(T), bk128 = 128 / (int)sizeof(T);
     const int pad64 = (P.CK + bk64 - 1) / bk64 * bk64, pad128 = (P.CK + bk128 - 1) / bk128 * bk128;
-    const bool use128 = pad128 <= pad64 + pad64 / 32;
+    bool use128 = pad128 <= pad64 + pad64 / 32;
+    if (const char* e = getenv("BGAMD_BKB")) use128 = atoi(e) == 128;  // tuning knob
+    // The LDS-DMA ring measured no faster than register staging on this workload (round 1:
+    // 423 vs 503 TFLOP/s FLOP-weighted forward), so it is opt-in.
+    static const bool no_dma = getenv("BGAMD_DMA") == nullptr;
+    if constexpr (sizeof(T) == 2) {
+        if (!no_dma) {
+            if (use128) {
+                const size_t sh = 3 * 2 * TILE * 128;  // 96 KiB
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<128, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                hipLaunchKernelGGL((gemm_conv_dma_kernel<128, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+            } else {
+                const size_t sh = 3 * 2 * TILE * 64;  // 48 KiB
+                hipLaunchKernelGGL((gemm_conv_dma_kernel<64, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+            }
+            BG_CHECK_LAUNCH("gemm_conv_dma_kernel");
+            return BG_OK;
+        }
+    }
     if (use128) {
         const size_t sh = 2 * 2 * TILE * 128;
         hipLaunchKernelGGL((gemm_conv_kernel<T, 128>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);

@@ -77,6 +77,11 @@ def _f64(*shape, device):
     return torch.zeros(shape, dtype=torch.float64, device=device)
 
 
+def _e32(*shape, device):
+    """Uninitialised fp32 scratch for buffers a kernel writes completely (no fill launch)."""
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
 # ------------------------------------------------------------------ layout boundary
 class ToInternal(torch.autograd.Function):
     """NCHW fp32 (module boundary, as the reference passes tensors) -> NHWC compute dtype."""
@@ -224,8 +229,7 @@ class NormActFn(torch.autograd.Function):
         groups = n if kind == "instance" else 1
         mean = rstd = scale = shift = None
         if kind != "identity":
-            mean, rstd = _f32(groups, c, device=dev), _f32(groups, c, device=dev)
-            scale, shift = _f32(groups, c, device=dev), _f32(groups, c, device=dev)
+            mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
             gptr = None if gslot is None else arena.master_ptr(gslot)
             bptr = None if bslot is None else arena.master_ptr(bslot)
             if use_batch_stats:
@@ -272,7 +276,7 @@ class NormActFn(torch.autograd.Function):
             s = _f64(2, groups, c, device=dev)
             L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
                    mean.data_ptr(), rstd.data_ptr(), rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
-            coef = _f32(3, groups, c, device=dev)
+            coef = _e32(3, groups, c, device=dev)
             dg = db = None
             if want_affine_grads:
                 arena.ensure_grad(gslot)
