@@ -33,7 +33,7 @@ _SIGS = {
     "bg_conv2d_fwd": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_data": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
-    "bg_transpose_krsc": [c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
+    "bg_pack_conv_weights": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
     "bg_dwconv3x3_fwd": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_data": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_weight": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
@@ -67,7 +67,7 @@ _SIGS = {
                      c_f32, c_vp],
     "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["bg_last_error"])
+EXPORTS = sorted(list(_SIGS) + ["bg_last_error", "bg_conv_weight_kpad"])
 
 _lib = None
 
@@ -88,10 +88,17 @@ def load():
         fn.restype = c_i32
     lib.bg_last_error.argtypes = []
     lib.bg_last_error.restype = C.c_char_p
+    lib.bg_conv_weight_kpad.argtypes = [c_i32]
+    lib.bg_conv_weight_kpad.restype = c_i32
     if lib.bg_abi_version() != ABI_VERSION:
         raise RuntimeError("bias_gan_amd: libbgamd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
+
+
+def kpad(dtype: torch.dtype) -> int:
+    """Reduction-dimension padding granule of the packed conv weight copies."""
+    return load().bg_conv_weight_kpad(dt(dtype))
 
 
 def dt(dtype: torch.dtype) -> int:

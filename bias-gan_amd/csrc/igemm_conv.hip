@@ -45,6 +45,9 @@ struct GemmConvParams {
     int transposed;
     long long M;  // N*OH*OW
     int tiles_c, tiles_p;
+    int CKp;       // K stride of one tap inside the (zero-padded) weight copy
+    int in_bytes;  // exact extent of the activation operand (buffer-load range check)
+    int w_bytes;
 };
 
 template <int BKB>
@@ -96,17 +99,23 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wav
     }
 }
 
+// Offsets into the operands are 32-bit byte offsets fed to buffer loads: the
+// hardware range check (num_records = exact byte size of the tensor) returns
+// zeros for any offset outside, so padding taps, rows beyond M and weight rows
+// beyond Cout simply carry the marker OOB -- no per-lane predication, no zero
+// fill code, and no 64-bit address arithmetic in the K loop.
+constexpr int OOB = (int)0x80000000;
+
 template <typename T, int BKB>
 __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
-    constexpr int VEC = 16 / sizeof(T);
-    constexpr int BK = BKB / sizeof(T);  // K elements per step
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BK = BKB / ES;         // K elements per step
     constexpr int CPR = BKB / 16;        // 16-byte chunks per tile row
     constexpr int RPP = NTHREADS / CPR;  // rows per load pass
     constexpr int NPASS = TILE / RPP;
     constexpr int TILE_BYTES = TILE * BKB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf][A|B][TILE_BYTES]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -130,16 +139,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
     const int row0 = tid / CPR;
     const int RS = P.KH * P.KW;
 
-    // per-thread row bookkeeping (fixed for the whole K loop).  The gather address of
-    // a row for tap (r,s) is  row_off + tap_delta(r,s) + c  with a wave-uniform
-    // tap_delta, so the K loop does one 64-bit add and two compares per row.
-    long long pix_off[NPASS];  // element offset of the tap-(0,0) source pixel (may be "negative" = outside)
-    long long pix_noff[NPASS];
-    int pix_h[NPASS], pix_w[NPASS];
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.in), 0, P.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.w), 0, P.w_bytes, 0x00020000);
+
+    // per-thread row bookkeeping, fixed for the whole K loop
+    int pix_base[NPASS];  // byte offset of the tap-(0,0) source pixel (+ this thread's chunk); only meaningful when valid
+    int pix_n[NPASS], pix_h[NPASS], pix_w[NPASS];
     bool pix_ok[NPASS];
-    long long w_roff[NPASS];
-    bool w_ok[NPASS];
-    const bool unit_stride_t = P.transposed && P.stride == 1;
+    int w_base[NPASS];    // byte offset of (co, tap 0, c = chunk) or OOB
+    const bool direct = !P.transposed || P.stride == 1;  // source pixel = base + uniform tap delta
+    const int sgn = P.transposed ? -1 : 1;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const long long p = p_base + row0 + i * RPP;
@@ -148,8 +157,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
         const unsigned ohw = (unsigned)(P.OH * P.OW);
         const unsigned n = pp / ohw;
         const unsigned rem = pp - n * ohw;
-        const int oh = (int)(rem / (unsigned)P.OW), ow = (int)(rem - (rem / (unsigned)P.OW) * (unsigned)P.OW);
-        pix_noff[i] = (long long)n * P.IH * P.IW;
+        const unsigned q = rem / (unsigned)P.OW;
+        const int oh = (int)q, ow = (int)(rem - q * (unsigned)P.OW);
+        pix_n[i] = (int)n;
         if (!P.transposed) {
             pix_h[i] = oh * P.stride - P.pad;
             pix_w[i] = ow * P.stride - P.pad;
@@ -157,57 +167,62 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
             pix_h[i] = oh + P.pad;
             pix_w[i] = ow + P.pad;
         }
-        pix_off[i] = (pix_noff[i] + (long long)pix_h[i] * P.IW + pix_w[i]) * P.ldi;
+        pix_base[i] = (((int)n * P.IH + pix_h[i]) * P.IW + pix_w[i]) * P.ldi * ES + chunk * 16;
         const int co = c_base + row0 + i * RPP;
-        w_ok[i] = co < P.NO;
-        w_roff[i] = (long long)(w_ok[i] ? co : 0) * RS * P.CK;
+        w_base[i] = co < P.NO ? co * RS * P.CKp * ES + chunk * 16 : OOB;
     }
 
-    const T* in = reinterpret_cast<const T*>(P.in);
-    const T* wt = reinterpret_cast<const T*>(P.w);
-
     Chunk<T> ra[NPASS], rb[NPASS];
-
     const int ksteps_per_tap = (P.CK + BK - 1) / BK;
     const int KT = RS * ksteps_per_tap;
 
-    auto issue_loads = [&](int kt) {
-        const int tap = kt / ksteps_per_tap;
-        const int c = (kt - tap * ksteps_per_tap) * BK + chunk * VEC;
-        const int r = tap / P.KW, s = tap - r * P.KW;
-        const bool c_ok = c < P.CK;
+    // load cursor: runs one K-step ahead of the MFMAs
+    int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
+    int va[NPASS], vb[NPASS];  // current byte offsets (advance by BKB per K-step inside a tap)
+    auto start_tap = [&]() {
+        const int dh = sgn * l_tap_r * P.dil, dw_ = sgn * l_tap_s * P.dil;
+        const int tap_delta = (dh * P.IW + dw_) * P.ldi * ES;  // wave-uniform
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            // weights (A operand)
-            if (w_ok[i] && c_ok) ra[i].load(wt + w_roff[i] + (long long)tap * P.CK + c);
-            else ra[i].zero();
-            // pixels (B operand)
-            bool ok = pix_ok[i] && c_ok;
-            if (!P.transposed || unit_stride_t) {
-                const int dh = P.transposed ? -r * P.dil : r * P.dil, dw_ = P.transposed ? -s * P.dil : s * P.dil;
+            va[i] = w_base[i] == OOB ? OOB : w_base[i] + l_tap * P.CKp * ES;
+            if (direct) {
                 const int ih = pix_h[i] + dh, iw = pix_w[i] + dw_;
-                ok = ok && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
-                const long long tap_delta = ((long long)dh * P.IW + dw_) * P.ldi;  // wave-uniform
-                if (ok) rb[i].load(in + pix_off[i] + tap_delta + c);
-                else rb[i].zero();
-            } else {
-                const int th = pix_h[i] - r * P.dil, tw = pix_w[i] - s * P.dil;
-                ok = ok && th >= 0 && tw >= 0;
+                const bool ok = pix_ok[i] && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
+                vb[i] = ok ? pix_base[i] + tap_delta : OOB;
+            } else {  // strided data gradient: only source pixels on the stride lattice contribute
+                const int th = pix_h[i] - l_tap_r * P.dil, tw = pix_w[i] - l_tap_s * P.dil;
+                bool ok = pix_ok[i] && th >= 0 && tw >= 0;
                 const int ih = th / P.stride, iw = tw / P.stride;
                 ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
-                if (ok) rb[i].load(in + (pix_noff[i] + (long long)ih * P.IW + iw) * P.ldi + c);
-                else rb[i].zero();
+                vb[i] = ok ? ((pix_n[i] * P.IH + ih) * P.IW + iw) * P.ldi * ES + chunk * 16 : OOB;
             }
         }
     };
+    auto issue_loads = [&]() {
+        if (l_ks == 0) start_tap();
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            ra[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, va[i], 0, 0));
+            rb[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vb[i], 0, 0));
+            va[i] += BKB;  // OOB + small stays out of range
+            vb[i] += BKB;
+        }
+        if (++l_ks == ksteps_per_tap) {
+            l_ks = 0;
+            ++l_tap;
+            if (++l_tap_s == P.KW) { l_tap_s = 0; ++l_tap_r; }
+        }
+    };
+    int lds_w[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) lds_w[i] = lds_off<BKB>(row0 + i * RPP, chunk);
     auto write_lds = [&](int buf) {
         char* sA = smem + buf * 2 * TILE_BYTES;
         char* sB = sA + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const int row = row0 + i * RPP;
-            ra[i].store(reinterpret_cast<T*>(sA + lds_off<BKB>(row, chunk)));
-            rb[i].store(reinterpret_cast<T*>(sB + lds_off<BKB>(row, chunk)));
+            ra[i].store(reinterpret_cast<T*>(sA + lds_w[i]));
+            rb[i].store(reinterpret_cast<T*>(sB + lds_w[i]));
         }
     };
 
@@ -217,13 +232,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(0);
+    issue_loads();
     write_lds(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
-        if (more) issue_loads(kt + 1);  // global loads in flight under the MFMAs
+        if (more) issue_loads();  // global loads in flight under the MFMAs
         const char* sA = smem + cur * 2 * TILE_BYTES;
         mma_slab<T, BKB>(sA, sA + TILE_BYTES, wave_c, wave_p, lane, acc);
         if (more) write_lds(cur ^ 1);
@@ -260,174 +275,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
             } else {
                 *reinterpret_cast<f32x4*>(dst) = v;
             }
-        }
-    }
-}
-
-// ---------------------------------------------------- LDS-DMA forward/dgrad ----
-// Same tile, swizzle, MFMA schedule and epilogue as gemm_conv_kernel, but the
-// operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
-// instruction) into a ring of NBUF stages, two K-steps ahead of the MFMAs:
-//   * no staging VGPRs, no ds_write pass;
-//   * one raw s_barrier per K-step, loads stay in flight across it and are retired
-//     with a COUNTED s_waitcnt vmcnt (never 0 inside the loop);
-//   * the LDS image of a DMA is lane-linear, so the XOR swizzle is applied to the
-//     SOURCE chunk each lane fetches (and to the fragment reads, as before);
-//   * rows that fall into padding / beyond the tensor fetch from a 16-byte zero
-//     constant instead (LDS-DMA cannot predicate a lane's write).
-__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int BKB, int NBUF>
-__global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams P) {
-    typedef bf16_t T;
-    constexpr int VEC = 8;
-    constexpr int BK = BKB / 2;
-    constexpr int CPR = BKB / 16;   // chunks per row
-    constexpr int RPG = 64 / CPR;   // tile rows covered by one wave-wide DMA (1 KiB)
-    constexpr int NG = 32 / RPG;    // DMAs per operand per wave per K-step (a wave stages 32 rows)
-    constexpr int GROUP = 2 * NG;   // VMEM ops per wave per K-step
-    constexpr int TILE_BYTES = TILE * BKB;
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-    constexpr int DIST = NBUF - 1;  // K-steps in flight ahead of the MFMAs
-    static_assert(DIST == 2, "the counted waits below assume two K-steps of prefetch");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_c = wave >> 1, wave_p = wave & 1;
-
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-    }
-    const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
-    const long long p_base = (long long)tile_p * TILE;
-    const int c_base = tile_c * TILE;
-    const int RS = P.KH * P.KW;
-
-    const int lr = lane / CPR, lc = lane % CPR;
-    const T* in = reinterpret_cast<const T*>(P.in);
-    const T* wt = reinterpret_cast<const T*>(P.w);
-    const T* zsrc = reinterpret_cast<const T*>(g_zero16);
-
-    long long pix_off[NG], pix_noff[NG], w_roff[NG];
-    int pix_h[NG], pix_w[NG], chk[NG];
-    bool pix_ok[NG], w_ok[NG];
-    const bool unit_stride_t = P.transposed && P.stride == 1;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int row = wave * 32 + g * RPG + lr;  // row inside the 128-row tile (same for A and B)
-        chk[g] = (BKB == 64) ? (lc ^ ((0 - (row >> 2)) & 3)) : (lc ^ ((row >> 1) & 7));
-        const long long p = p_base + row;
-        pix_ok[g] = p < P.M;
-        const unsigned pp = pix_ok[g] ? (unsigned)p : 0u;
-        const unsigned ohw = (unsigned)(P.OH * P.OW);
-        const unsigned n = pp / ohw;
-        const unsigned rem = pp - n * ohw;
-        const unsigned q = rem / (unsigned)P.OW;
-        const int oh = (int)q, ow = (int)(rem - q * (unsigned)P.OW);
-        pix_noff[g] = (long long)n * P.IH * P.IW;
-        if (!P.transposed) {
-            pix_h[g] = oh * P.stride - P.pad;
-            pix_w[g] = ow * P.stride - P.pad;
-        } else {
-            pix_h[g] = oh + P.pad;
-            pix_w[g] = ow + P.pad;
-        }
-        pix_off[g] = (pix_noff[g] + (long long)pix_h[g] * P.IW + pix_w[g]) * P.ldi;
-        const int co = c_base + row;
-        w_ok[g] = co < P.NO;
-        w_roff[g] = (long long)(w_ok[g] ? co : 0) * RS * P.CK;
-    }
-
-    const int ksteps_per_tap = (P.CK + BK - 1) / BK;
-    const int KT = RS * ksteps_per_tap;
-
-    auto issue = [&](int kt, int buf) {
-        const int tap = kt / ksteps_per_tap;
-        const int c0 = (kt - tap * ksteps_per_tap) * BK;
-        const int r = tap / P.KW, s = tap - r * P.KW;
-        char* stage = smem + buf * STAGE_BYTES + wave * 32 * BKB;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int c = c0 + chk[g] * VEC;
-            const bool c_ok = c < P.CK;
-            const T* srcA = (w_ok[g] && c_ok) ? wt + w_roff[g] + (long long)tap * P.CK + c : zsrc;
-            __builtin_amdgcn_global_load_lds((glb_ptr)srcA, (lds_ptr)(stage + g * RPG * BKB), 16, 0, 0);
-            bool ok = pix_ok[g] && c_ok;
-            const T* srcB;
-            if (!P.transposed || unit_stride_t) {
-                const int dh = P.transposed ? -r * P.dil : r * P.dil, dw_ = P.transposed ? -s * P.dil : s * P.dil;
-                const int ih = pix_h[g] + dh, iw = pix_w[g] + dw_;
-                ok = ok && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
-                srcB = in + pix_off[g] + ((long long)dh * P.IW + dw_) * P.ldi + c;
-            } else {
-                const int th = pix_h[g] - r * P.dil, tw = pix_w[g] - s * P.dil;
-                ok = ok && th >= 0 && tw >= 0;
-                const int ih = th / P.stride, iw = tw / P.stride;
-                ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
-                srcB = in + (pix_noff[g] + (long long)ih * P.IW + iw) * P.ldi + c;
-            }
-            if (!ok) srcB = zsrc;
-            __builtin_amdgcn_global_load_lds((glb_ptr)srcB, (lds_ptr)(stage + TILE_BYTES + g * RPG * BKB), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    issue(0, 0);
-    if (KT > 1) issue(1, 1);
-    int buf = 0, nbuf = DIST % NBUF;
-    for (int kt = 0; kt < KT; ++kt) {
-        // retire this wave's DMAs of step kt (leave step kt+1's in flight), then meet the others
-        if (kt + 1 < KT) wait_vmcnt<GROUP>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        // stage (kt+2): its ring slot was last read in iteration kt-1, which every wave has left
-        if (kt + DIST < KT) issue(kt + DIST, nbuf);
-        const char* sA = smem + buf * STAGE_BYTES;
-        mma_slab<T, BKB>(sA, sA + TILE_BYTES, wave_c, wave_p, lane, acc);
-        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
-        nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
-    }
-
-    T* out = reinterpret_cast<T*>(P.out);
-    const int r16 = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long p = p_base + wave_p * 64 + j * 16 + r16;
-        if (p >= P.M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
-            if (co >= P.NO) continue;
-            f32x4 v = acc[i][j];
-            if (P.bias) {
-                v[0] += P.bias[co + 0];
-                v[1] += P.bias[co + 1];
-                v[2] += P.bias[co + 2];
-                v[3] += P.bias[co + 3];
-            }
-            bf16x4 o;
-            o[0] = (bf16_t)v[0];
-            o[1] = (bf16_t)v[1];
-            o[2] = (bf16_t)v[2];
-            o[3] = (bf16_t)v[3];
-            *reinterpret_cast<bf16x4*>(out + p * P.ldo + co) = o;
         }
     }
 }
@@ -519,7 +366,19 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     const int wave_m = wave >> 1, wave_n = wave & 1;
 
     const int RS = P.KH * P.KW;
-    int bid = blockIdx.x;
+    // 1-D grid of (split, tile) pairs.  Workgroups with the same id % 8 share an XCD (and its
+    // L2); give each XCD a CONTIGUOUS range of the split-major order, so the tiles that re-read
+    // one split's pixels (dy for every ci tile, x for every co tile) hit in one L2 instead of
+    // being fetched from HBM by all eight.
+    const int tiles = P.tiles_co * P.tiles_ci * RS;
+    int lin = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = lin & 7, k = lin >> 3;
+        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int split = lin / tiles;
+    int bid = lin - split * tiles;
     const int tile_ci = bid % P.tiles_ci;
     bid /= P.tiles_ci;
     const int tap = bid % RS;
@@ -527,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     const int r = tap / P.KW, s = tap - r * P.KW;
     const int co_base = tile_co * TILE, ci_base = tile_ci * TILE;
 
-    const long long p_begin = (long long)blockIdx.y * P.pix_per_split;
+    const long long p_begin = (long long)split * P.pix_per_split;
     long long p_end = p_begin + P.pix_per_split;
     if (p_end > P.M) p_end = P.M;
     if (p_begin >= p_end) return;  // uniform per block
@@ -618,22 +477,35 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
         }
 }
 
-// ---------------------------------------------------------- batched transpose
+// ------------------------------------------------------- batched weight packing
+// Per dense-conv layer: src [K][RS][C] (the flat bf16/fp32 copy of the master weights)
+//   -> dst_k [K][RS][Cp]  forward operand, reduction dim zero-padded to the K-step granule
+//   -> dst_t [C][RS][Kp]  data-gradient operand (CRSK), likewise padded
+// so the GEMM K loop never needs a tail predicate.  tbl: 8 int64 per layer
+// (src_off, dk_off, dt_off, K, RS, C, Cp, Kp), element units.
 template <typename T>
-__global__ void transpose_krsc_kernel(const T* __restrict__ src, T* __restrict__ dst, const long long* tbl) {
-    const long long* e = tbl + (long long)blockIdx.y * 5;
-    const long long so = e[0], dof = e[1], K = e[2], RS = e[3], C = e[4];
-    const long long total = K * RS * C;
-    // dst[c][rs][k] = src[k][rs][c]; index over dst so writes are coalesced
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+__global__ void pack_conv_weights_kernel(const T* __restrict__ src, T* __restrict__ dst_k, T* __restrict__ dst_t,
+                                         const long long* tbl) {
+    const long long* e = tbl + (long long)blockIdx.y * 8;
+    const long long so = e[0], dk = e[1], dt = e[2], K = e[3], RS = e[4], C = e[5], Cp = e[6], Kp = e[7];
+    const long long nk = K * RS * Cp, nt = C * RS * Kp;
+    const T zero = Elem<T>::from_f(0.f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nk + nt;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long k = i % K;
-        const long long t = i / K;
-        const long long rs = t % RS;
-        const long long c = t / RS;
-        dst[dof + i] = src[so + (k * RS + rs) * C + c];
+        if (i < nk) {
+            const long long c = i % Cp, t = i / Cp;  // t = k*RS + rs
+            dst_k[dk + i] = c < C ? src[so + t * C + c] : zero;
+        } else {
+            const long long j = i - nk;
+            const long long k = j % Kp, t = j / Kp;
+            const long long rs = t % RS, c = t / RS;
+            dst_t[dt + j] = k < K ? src[so + (k * RS + rs) * C + c] : zero;
+        }
     }
 }
+
+inline int kpad_of(int dtype) { return dtype == BG_BF16 ? 64 : 32; }
+inline int pad_k(int c, int dtype) { const int g = kpad_of(dtype); return (c + g - 1) / g * g; }
 
 int check_conv_desc(const bg_conv_desc* d, const char* who) {
     BG_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
@@ -660,6 +532,16 @@ int check_conv_desc(const bg_conv_desc* d, const char* who) {
 template <typename T>
 int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     GemmConvParams P = P0;
+    const int dt = sizeof(T) == 2 ? BG_BF16 : BG_F32;
+    P.CKp = pad_k(P.CK, dt);
+    const long long in_bytes = (((long long)P.N * P.IH * P.IW - 1) * P.ldi + P.CK) * (long long)sizeof(T);
+    const long long w_bytes = (long long)P.NO * P.KH * P.KW * P.CKp * (long long)sizeof(T);
+    if (in_bytes >= (1LL << 31) || w_bytes >= (1LL << 31)) {
+        bg_set_error("conv: operand larger than 2 GiB (32-bit buffer offsets)");
+        return BG_E_ARG;
+    }
+    P.in_bytes = (int)in_bytes;
+    P.w_bytes = (int)w_bytes;
     P.tiles_c = (P.NO + TILE - 1) / TILE;
     P.tiles_p = (int)((P.M + TILE - 1) / TILE);
     const long long nblk = (long long)P.tiles_c * P.tiles_p;
@@ -673,24 +555,6 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     const int pad64 = (P.CK + bk64 - 1) / bk64 * bk64, pad128 = (P.CK + bk128 - 1) / bk128 * bk128;
     bool use128 = pad128 <= pad64 + pad64 / 32;
     if (const char* e = getenv("BGAMD_BKB")) use128 = atoi(e) == 128;  // tuning knob
-    // The LDS-DMA ring measured no faster than register staging on this workload (round 1:
-    // 423 vs 503 TFLOP/s FLOP-weighted forward), so it is opt-in.
-    static const bool no_dma = getenv("BGAMD_DMA") == nullptr;
-    if constexpr (sizeof(T) == 2) {
-        if (!no_dma) {
-            if (use128) {
-                const size_t sh = 3 * 2 * TILE * 128;  // 96 KiB
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<128, 3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-                hipLaunchKernelGGL((gemm_conv_dma_kernel<128, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
-            } else {
-                const size_t sh = 3 * 2 * TILE * 64;  // 48 KiB
-                hipLaunchKernelGGL((gemm_conv_dma_kernel<64, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
-            }
-            BG_CHECK_LAUNCH("gemm_conv_dma_kernel");
-            return BG_OK;
-        }
-    }
     if (use128) {
         const size_t sh = 2 * 2 * TILE * 128;
         hipLaunchKernelGGL((gemm_conv_kernel<T, 128>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
@@ -751,42 +615,48 @@ extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const 
     P.tiles_ci = (d->Cin + TILE - 1) / TILE;
     const long long tiles = (long long)P.tiles_co * P.tiles_ci * d->KH * d->KW;
     // enough pixel splits to put ~1024 workgroups on the chip, each with >= 256 pixels
-    long long splits = (1024 + tiles - 1) / tiles;
+    // Pixel splits: two 256-thread workgroups fit a CU (VGPRs), so one full wave of the chip
+    // is 512 workgroups.  Fill about one wave: more splits only add float-atomic traffic
+    // (every split adds a whole copy of dW), fewer leave CUs idle.
+    static const long long target_wgs = getenv("BGAMD_WGRAD_TARGET") ? atoll(getenv("BGAMD_WGRAD_TARGET")) : 512;
+    long long splits = tiles < 256 ? target_wgs / tiles : (2 * target_wgs + tiles - 1) / tiles;  // many tiles: balance the tail
     const long long max_splits = (P.M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
     P.pix_per_split = ((P.M + splits - 1) / splits + WG_PIX - 1) / WG_PIX * WG_PIX;
     splits = (P.M + P.pix_per_split - 1) / P.pix_per_split;
-    BG_CHECK_ARG(tiles <= 0x7fffffffLL, "bg_conv2d_bwd_weight: grid too large");
+    BG_CHECK_ARG(tiles * splits <= 0x7fffffffLL, "bg_conv2d_bwd_weight: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == BG_BF16) {
         const size_t sh = 2 * 2 * WG_PIX * (TILE * 2 + 64);
-        hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)tiles, (unsigned)splits), dim3(NTHREADS), sh, st, P);
+        hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), sh, st, P);
     } else {
         const size_t sh = 2 * 2 * WG_PIX * (TILE * 4 + 64);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)tiles, (unsigned)splits), dim3(NTHREADS), sh, st, P);
+        hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), sh, st, P);
     }
     BG_CHECK_LAUNCH("wgrad_kernel");
     if (dbias) return bg_colsum(d->dtype, dy, d->ldy, P.M, d->Cout, 1, 1.0f, dbias, stream);
     return BG_OK;
 }
 
-extern "C" int bg_transpose_krsc(int32_t dtype, const void* src, void* dst, const int64_t* tbl, int32_t n_layers,
-                                 int64_t max_elems, void* stream) {
-    BG_CHECK_ARG(dtype_ok(dtype) && src && dst && tbl && n_layers > 0 && max_elems > 0, "bg_transpose_krsc: bad args");
-    BG_CHECK_ARG(n_layers <= 65535, "bg_transpose_krsc: too many layers");
+extern "C" int bg_conv_weight_kpad(int32_t dtype) { return dtype_ok(dtype) ? kpad_of(dtype) : BG_E_ARG; }
+
+extern "C" int bg_pack_conv_weights(int32_t dtype, const void* src, void* dst_krsc, void* dst_crsk, const int64_t* tbl,
+                                    int32_t n_layers, int64_t max_elems, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && src && dst_krsc && dst_crsk && tbl && n_layers > 0 && max_elems > 0,
+                 "bg_pack_conv_weights: bad args");
+    BG_CHECK_ARG(n_layers <= 65535, "bg_pack_conv_weights: too many layers");
     long long bx = (max_elems + 255) / 256;
     if (bx > 1024) bx = 1024;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == BG_BF16)
-        hipLaunchKernelGGL((transpose_krsc_kernel<bf16_t>), dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, st,
-                           (const bf16_t*)src, (bf16_t*)dst, (const long long*)tbl);
+        hipLaunchKernelGGL((pack_conv_weights_kernel<bf16_t>), dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, st,
+                           (const bf16_t*)src, (bf16_t*)dst_krsc, (bf16_t*)dst_crsk, (const long long*)tbl);
     else
-        hipLaunchKernelGGL((transpose_krsc_kernel<float>), dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, st,
-                           (const float*)src, (float*)dst, (const long long*)tbl);
-    BG_CHECK_LAUNCH("transpose_krsc_kernel");
+        hipLaunchKernelGGL((pack_conv_weights_kernel<float>), dim3((unsigned)bx, (unsigned)n_layers), dim3(256), 0, st,
+                           (const float*)src, (float*)dst_krsc, (float*)dst_crsk, (const long long*)tbl);
+    BG_CHECK_LAUNCH("pack_conv_weights_kernel");
     return BG_OK;
 }

@@ -37,7 +37,7 @@ def pad_to(c: int, v: int) -> int:
 
 class ParamSlot:
     """Where one nn.Parameter lives inside the arenas."""
-    __slots__ = ("name", "param", "kind", "off", "numel", "phys_shape", "t_off", "krsc")
+    __slots__ = ("name", "param", "kind", "off", "numel", "phys_shape", "t_off", "k_off", "krsc")
 
     def __init__(self, name, param, kind, phys_shape):
         self.name, self.param, self.kind, self.phys_shape = name, param, kind, tuple(phys_shape)
@@ -45,8 +45,9 @@ class ParamSlot:
         for s in phys_shape:
             self.numel *= s
         self.off = -1
-        self.t_off = -1   # offset inside the transposed (CRSK) arena, dense convs only
-        self.krsc = None  # (K, RS, C) for dense convs
+        self.t_off = -1   # offset inside the packed CRSK arena, dense convs only
+        self.k_off = -1   # offset inside the packed KRSC arena, dense convs only
+        self.krsc = None  # (K, RS, C, Cp, Kp) for dense convs
 
 
 _ARENA_OF = {}  # id(param) -> weakref to its arena
@@ -88,24 +89,31 @@ class Arena:
             raise RuntimeError("bias_gan_amd: module has no parameters")
         self.device = dev
         off = 0
-        t_off = 0
+        t_off = k_off = 0
+        g = L.kpad(compute_dtype)
         for s in self.slots:
             s.off = off
             off += pad_to(s.numel, 64)  # 256-byte aligned segments
             if s.kind == "conv":
                 k, r, q, c = s.phys_shape
-                s.krsc = (k, r * q, c)
-                s.t_off = t_off
-                t_off += pad_to(s.numel, 64)
+                cp, kp = pad_to(c, g), pad_to(k, g)
+                s.krsc = (k, r * q, c, cp, kp)
+                s.k_off, s.t_off = k_off, t_off
+                k_off += pad_to(k * r * q * cp, 64)
+                t_off += pad_to(c * r * q * kp, 64)
         self.numel = off
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.lp = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
-        self.tr = torch.zeros(max(t_off, 1), dtype=compute_dtype, device=dev)
-        tbl = [[s.off, s.t_off, s.krsc[0], s.krsc[1], s.krsc[2]] for s in self.slots if s.kind == "conv"]
-        self.tr_tbl = torch.tensor(tbl if tbl else [[0, 0, 0, 0, 0]], dtype=torch.int64, device=dev)
+        # packed operand copies of the dense conv weights (reduction dim zero-padded)
+        self.wk = torch.zeros(max(k_off, 1), dtype=compute_dtype, device=dev)
+        self.wt = torch.zeros(max(t_off, 1), dtype=compute_dtype, device=dev)
+        tbl = [[s.off, s.k_off, s.t_off, s.krsc[0], s.krsc[1], s.krsc[2], s.krsc[3], s.krsc[4]]
+               for s in self.slots if s.kind == "conv"]
+        self.tr_tbl = torch.tensor(tbl if tbl else [[0] * 8], dtype=torch.int64, device=dev)
         self.tr_layers = len(tbl)
-        self.tr_max = max([s.numel for s in self.slots if s.kind == "conv"] + [1])
+        self.tr_max = max([s.krsc[0] * s.krsc[1] * s.krsc[3] + s.krsc[2] * s.krsc[1] * s.krsc[4]
+                           for s in self.slots if s.kind == "conv"] + [1])
         # move the current values in and re-point the Parameters at arena views
         with torch.no_grad():
             for s in self.slots:
@@ -172,17 +180,20 @@ class Arena:
             L.call("bg_cast_f32_to_bf16", self.master.data_ptr(), self.lp.data_ptr(), self.numel)
         if self.tr_layers:
             src = self.lp if self.lp is not None else self.master
-            L.call("bg_transpose_krsc", L.dt(self.compute_dtype), src.data_ptr(), self.tr.data_ptr(),
-                   self.tr_tbl.data_ptr(), self.tr_layers, self.tr_max)
+            L.call("bg_pack_conv_weights", L.dt(self.compute_dtype), src.data_ptr(), self.wk.data_ptr(),
+                   self.wt.data_ptr(), self.tr_tbl.data_ptr(), self.tr_layers, self.tr_max)
 
     def weight_ptr(self, s: ParamSlot) -> int:
-        """Device pointer of the compute-dtype copy of a parameter (KRSC / [R,S,C])."""
+        """Device pointer of the compute-dtype operand copy of a parameter: packed KRSC for
+        dense convs, the flat [R,S,C] copy for depthwise weights."""
+        if s.kind == "conv":
+            return self.wk.data_ptr() + self.wk.element_size() * s.k_off
         if self.lp is not None:
             return self.lp.data_ptr() + 2 * s.off
         return self.master.data_ptr() + 4 * s.off
 
     def weight_t_ptr(self, s: ParamSlot) -> int:
-        return self.tr.data_ptr() + self.tr.element_size() * s.t_off
+        return self.wt.data_ptr() + self.wt.element_size() * s.t_off
 
     def master_ptr(self, s: ParamSlot) -> int:
         return self.master.data_ptr() + 4 * s.off

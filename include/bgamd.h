@@ -28,9 +28,12 @@
  *     (the performance path), BG_F32 = everything fp32 (the parity path).
  *     Statistics, losses, gradients of parameters and optimiser state are
  *     always fp32 (statistic sums fp64).
- *   - conv weights: forward uses [Cout][KH][KW][Cin] ("KRSC"); bwd_data uses the
- *     transposed copy [Cin][KH][KW][Cout] ("CRSK") made by bg_transpose_krsc.
- *     Depthwise weights are [KH][KW][C].
+ *   - conv weights: forward reads [Cout][KH][KW][Cin_k] ("KRSC") and bwd_data the
+ *     transposed copy [Cin][KH][KW][Cout_k] ("CRSK"), where the innermost
+ *     (reduction) dimension is zero-padded to a multiple of bg_conv_weight_kpad()
+ *     elements (64 for bf16, 32 for f32) so the GEMM K loop needs no tail
+ *     predicate; bg_pack_conv_weights builds both copies from the dense fp32 /
+ *     bf16 master layout [Cout][KH][KW][Cin].  Depthwise weights are [KH][KW][C].
  */
 #ifndef BGAMD_H
 #define BGAMD_H
@@ -69,19 +72,22 @@ typedef struct bg_conv_desc {
     int32_t ldx, ldy;
 } bg_conv_desc;
 
-/* y = conv(x, w) (+ bias[Cout], fp32, may be NULL).  w: KRSC, dtype = d->dtype. */
+/* y = conv(x, w) (+ bias[Cout], fp32, may be NULL).  w: K-padded KRSC copy, dtype = d->dtype. */
 int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
-/* dx = conv_transpose(dy, w).  wt: CRSK copy of the weights.  Overwrites dx. */
+/* dx = conv_transpose(dy, w).  wt: K-padded CRSK copy of the weights.  Overwrites dx. */
 int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
 /* dw += x (*) dy, dw fp32 KRSC (accumulated with float atomics; caller zeroes it
  * once per backward pass).  dbias (fp32 [Cout], may be NULL) += sum over pixels of dy. */
 int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* stream);
 
-/* KRSC -> CRSK for a batch of layers in one launch.  tbl (device, n entries of 5
- * int64: src_off, dst_off, K, RS, C in elements) describes each layer inside the
- * flat buffers src/dst (same dtype). */
-int bg_transpose_krsc(int32_t dtype, const void* src, void* dst, const int64_t* tbl, int32_t n_layers,
-                      int64_t max_elems, void* stream);
+/* Reduction-dimension padding granule of the packed weight copies (elements). */
+int bg_conv_weight_kpad(int32_t dtype);
+/* Build the padded KRSC and CRSK copies for a batch of layers in one launch.  tbl
+ * (device, n entries of 8 int64: src_off, krsc_off, crsk_off, K, RS, C, Cp, Kp in
+ * elements; Cp/Kp = C/K rounded up to the granule) addresses each layer inside the
+ * flat buffers; max_elems = largest K*RS*Cp + C*RS*Kp over the layers. */
+int bg_pack_conv_weights(int32_t dtype, const void* src, void* dst_krsc, void* dst_crsk, const int64_t* tbl,
+                         int32_t n_layers, int64_t max_elems, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Depthwise 3x3 of SeparableConv2d_same, with fixed_padding folded in

@@ -38,8 +38,11 @@ for cin, cout, k, s, d, H, W, cnt in SHAPES:
     ldx = (cin + LDP - 1) // LDP * LDP if LDP else cin
     ldy = (cout + LDP - 1) // LDP * LDP if LDP else cout
     x = torch.randn(N, H, W, ldx, device=dev).bfloat16()[..., :cin]
-    w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).bfloat16()
-    wt = w.permute(3, 1, 2, 0).contiguous()
+    cp, kp = (cin + 63) // 64 * 64, (cout + 63) // 64 * 64
+    w = torch.zeros(cout, k, k, cp, device=dev, dtype=torch.bfloat16)
+    w[..., :cin] = (torch.randn(cout, k, k, cin, device=dev) * 0.05).bfloat16()
+    wt = torch.zeros(cin, k, k, kp, device=dev, dtype=torch.bfloat16)
+    wt[..., :cout] = w[..., :cin].permute(3, 1, 2, 0)
     y = torch.empty(N, Ho, Wo, ldy, device=dev, dtype=torch.bfloat16)[..., :cout]
     dy = torch.randn(N, Ho, Wo, ldy, device=dev).bfloat16()[..., :cout]
     dx = torch.empty(N, H, W, ldx, device=dev, dtype=torch.bfloat16)[..., :cin]

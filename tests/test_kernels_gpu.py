@@ -52,10 +52,29 @@ def from_nhwc(view, c):
 
 
 def krsc(w, dtype):
+    """Dense [Coutp][KH][KW][Cinp] copy (the master layout bg_pack_conv_weights reads)."""
     co, ci, kh, kw = w.shape
     out = torch.zeros(up(co, dtype), kh, kw, up(ci, dtype), dtype=dtype, device=DEV)
     out[:co, :, :, :ci] = w.permute(0, 2, 3, 1).to(dtype).to(DEV)
     return out
+
+
+def pack(wk, dtype):
+    """(K-padded KRSC, K-padded CRSK) operand copies through bg_pack_conv_weights."""
+    kp, kh, kw, cp = wk.shape
+    g = L.kpad(dtype)
+    cpp, kpp = (cp + g - 1) // g * g, (kp + g - 1) // g * g
+    dk = torch.full((kp * kh * kw * cpp,), 9.0, dtype=dtype, device=DEV)
+    dtt = torch.full((cp * kh * kw * kpp,), 9.0, dtype=dtype, device=DEV)
+    tbl = torch.tensor([[0, 0, 0, kp, kh * kw, cp, cpp, kpp]], dtype=torch.int64, device=DEV)
+    L.call("bg_pack_conv_weights", L.dt(dtype), wk.data_ptr(), dk.data_ptr(), dtt.data_ptr(), tbl.data_ptr(), 1,
+           dk.numel() + dtt.numel())
+    ref_k = torch.zeros(kp, kh * kw, cpp, dtype=dtype, device=DEV)
+    ref_k[:, :, :cp] = wk.view(kp, kh * kw, cp)
+    ref_t = torch.zeros(cp, kh * kw, kpp, dtype=dtype, device=DEV)
+    ref_t[:, :, :kp] = wk.view(kp, kh * kw, cp).permute(2, 1, 0)
+    assert torch.equal(dk.view_as(ref_k), ref_k) and torch.equal(dtt.view_as(ref_t), ref_t)
+    return dk, dtt
 
 
 def assert_close(got, ref, rel, what=""):
@@ -99,11 +118,12 @@ def test_conv2d_fwd_bwd(case, dtype, sliced):
     desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, k, s, p, d, ldx, ldy)
     xb, xv = to_nhwc(x, dtype, ldx, xoff)
     wk = krsc(wt, dtype)
+    wpk, wpt = pack(wk, dtype)
     bpad = torch.zeros(coutp, device=DEV)
     bpad[:cout] = bias.to(DEV)
     yb = torch.full((n, ho, wo, ldy), 7.0, dtype=dtype, device=DEV)
     yv = yb[..., yoff:]
-    L.call("bg_conv2d_fwd", desc, xv.data_ptr(), wk.data_ptr(), bpad.data_ptr(), yv.data_ptr())
+    L.call("bg_conv2d_fwd", desc, xv.data_ptr(), wpk.data_ptr(), bpad.data_ptr(), yv.data_ptr())
     ref = F.conv2d(x, wt, bias, s, p, d)
     assert_close(from_nhwc(yv, cout), ref, tol(dtype), "fwd")
     if sliced:  # nothing outside the slice was touched
@@ -117,14 +137,9 @@ def test_conv2d_fwd_bwd(case, dtype, sliced):
     wr = wt.clone().requires_grad_(True)
     F.conv2d(xr, wr, None, s, p, d).backward(go)
     gb, gv = to_nhwc(go, dtype, ldy, yoff)
-    # CRSK copy through the batched transpose entry point
-    wtt = torch.empty(cinp * k * k * coutp, dtype=dtype, device=DEV)
-    tbl = torch.tensor([[0, 0, coutp, k * k, cinp]], dtype=torch.int64, device=DEV)
-    L.call("bg_transpose_krsc", L.dt(dtype), wk.data_ptr(), wtt.data_ptr(), tbl.data_ptr(), 1, wk.numel())
-    assert torch.equal(wtt.view(cinp, k * k, coutp), wk.view(coutp, k * k, cinp).permute(2, 1, 0).contiguous())
     dxb = torch.full((n, h, w, ldx), 5.0, dtype=dtype, device=DEV)
     dxv = dxb[..., xoff:]
-    L.call("bg_conv2d_bwd_data", desc, gv.data_ptr(), wtt.data_ptr(), dxv.data_ptr())
+    L.call("bg_conv2d_bwd_data", desc, gv.data_ptr(), wpt.data_ptr(), dxv.data_ptr())
     assert_close(from_nhwc(dxv, cin), xr.grad, tol(dtype), "bwd_data")
     dw = torch.zeros(coutp, k, k, cinp, device=DEV)
     db = torch.zeros(coutp, device=DEV)
@@ -149,7 +164,8 @@ def test_conv_mfma_layout_asymmetric(dtype):
     desc, ho, wo = conv_desc(dtype, n, h, w, c, c, 1, 1, 0, 1, c, c)
     xb, xv = to_nhwc(x, dtype)
     yb = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
-    L.call("bg_conv2d_fwd", desc, xv.data_ptr(), krsc(wt, dtype).data_ptr(), None, yb.data_ptr())
+    wpk, _ = pack(krsc(wt, dtype), dtype)
+    L.call("bg_conv2d_fwd", desc, xv.data_ptr(), wpk.data_ptr(), None, yb.data_ptr())
     assert torch.equal(from_nhwc(yb, c), F.conv2d(x, wt))  # small integers: exact in bf16 too
 
 
