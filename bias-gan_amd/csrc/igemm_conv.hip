@@ -279,6 +279,188 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
     }
 }
 
+// ------------------------------------------------------- LDS-DMA variant ----
+// Same tiling, swizzle, MFMA schedule and epilogue, but the operands travel
+// global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction,
+// out-of-range lanes deliver zeros) into a ring of NBUF stages that runs two
+// K-steps ahead of the MFMAs: no staging VGPRs, no ds_write pass, one raw
+// s_barrier per K-step with the loads kept in flight across it behind a COUNTED
+// s_waitcnt vmcnt.  The LDS image of a DMA is lane-linear, so the XOR swizzle is
+// applied to the SOURCE chunk each lane fetches.
+// (non-template on purpose: hipcc's host pass rejects this target builtin inside a
+// dependent context with a silent substitution failure)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst, 16, voffset, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BKB, int NBUF>
+__global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams P) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BK = BKB / ES;
+    constexpr int CPR = BKB / 16;   // chunks per row
+    constexpr int RPG = 64 / CPR;   // tile rows covered by one wave-wide DMA (1 KiB)
+    constexpr int NG = 32 / RPG;    // DMAs per operand per wave per K-step (a wave stages 32 rows)
+    constexpr int GROUP = 2 * NG;   // VMEM ops per wave per K-step
+    constexpr int TILE_BYTES = TILE * BKB;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int DIST = NBUF - 1;  // K-steps in flight ahead of the MFMAs
+    static_assert(DIST == 2 || DIST == 3, "counted waits are written for 2 or 3 K-steps of prefetch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_c = wave >> 1, wave_p = wave & 1;
+
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
+    const long long p_base = (long long)tile_p * TILE;
+    const int c_base = tile_c * TILE;
+    const int RS = P.KH * P.KW;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.in), 0, P.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.w), 0, P.w_bytes, 0x00020000);
+
+    const int lr = lane / CPR, lc = lane % CPR;
+    int pix_base[NG], pix_n[NG], pix_h[NG], pix_w[NG], w_base[NG], chk16[NG];
+    bool pix_ok[NG];
+    const bool direct = !P.transposed || P.stride == 1;
+    const int sgn = P.transposed ? -1 : 1;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int row = wave * 32 + g * RPG + lr;  // row inside the 128-row tile (same for A and B)
+        const int chk = (BKB == 64) ? (lc ^ ((0 - (row >> 2)) & 3)) : (lc ^ ((row >> 1) & 7));
+        chk16[g] = chk * 16;
+        const long long p = p_base + row;
+        pix_ok[g] = p < P.M;
+        const unsigned pp = pix_ok[g] ? (unsigned)p : 0u;
+        const unsigned ohw = (unsigned)(P.OH * P.OW);
+        const unsigned n = pp / ohw;
+        const unsigned rem = pp - n * ohw;
+        const unsigned q = rem / (unsigned)P.OW;
+        const int oh = (int)q, ow = (int)(rem - q * (unsigned)P.OW);
+        pix_n[g] = (int)n;
+        if (!P.transposed) {
+            pix_h[g] = oh * P.stride - P.pad;
+            pix_w[g] = ow * P.stride - P.pad;
+        } else {
+            pix_h[g] = oh + P.pad;
+            pix_w[g] = ow + P.pad;
+        }
+        pix_base[g] = (((int)n * P.IH + pix_h[g]) * P.IW + pix_w[g]) * P.ldi * ES + chk16[g];
+        const int co = c_base + row;
+        w_base[g] = co < P.NO ? co * RS * P.CKp * ES + chk16[g] : OOB;
+    }
+
+    const int ksteps_per_tap = (P.CK + BK - 1) / BK;
+    const int KT = RS * ksteps_per_tap;
+
+    int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
+    int va[NG], vb[NG];
+    auto start_tap = [&]() {
+        const int dh = sgn * l_tap_r * P.dil, dw_ = sgn * l_tap_s * P.dil;
+        const int tap_delta = (dh * P.IW + dw_) * P.ldi * ES;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            va[g] = w_base[g] == OOB ? OOB : w_base[g] + l_tap * P.CKp * ES;
+            if (direct) {
+                const int ih = pix_h[g] + dh, iw = pix_w[g] + dw_;
+                const bool ok = pix_ok[g] && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
+                vb[g] = ok ? pix_base[g] + tap_delta : OOB;
+            } else {
+                const int th = pix_h[g] - l_tap_r * P.dil, tw = pix_w[g] - l_tap_s * P.dil;
+                bool ok = pix_ok[g] && th >= 0 && tw >= 0;
+                const int ih = th / P.stride, iw = tw / P.stride;
+                ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
+                vb[g] = ok ? ((pix_n[g] * P.IH + ih) * P.IW + iw) * P.ldi * ES + chk16[g] : OOB;
+            }
+        }
+    };
+    auto issue = [&](int buf) {
+        if (l_ks == 0) start_tap();
+        char* stage = smem + buf * STAGE_BYTES + wave * 32 * BKB;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            dma16(rs_w, stage + g * RPG * BKB, va[g]);
+            dma16(rs_in, stage + TILE_BYTES + g * RPG * BKB, vb[g]);
+            va[g] += BKB;
+            vb[g] += BKB;
+        }
+        if (++l_ks == ksteps_per_tap) {
+            l_ks = 0;
+            ++l_tap;
+            if (++l_tap_s == P.KW) { l_tap_s = 0; ++l_tap_r; }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    if (KT > 1) issue(1);
+    if (DIST > 2 && KT > 2) issue(2);
+    int buf = 0, nbuf = DIST % NBUF;
+    for (int kt = 0; kt < KT; ++kt) {
+        // retire this wave's DMAs of step kt (leave the later steps' in flight), then meet the others
+        const int ahead = KT - 1 - kt;  // steps issued beyond kt, capped by DIST-1
+        if (DIST > 2 && ahead >= 2) wait_vmcnt<2 * GROUP>();
+        else if (ahead >= 1) wait_vmcnt<GROUP>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        // stage kt+2: its ring slot was last read in iteration kt-1, which every wave has left
+        if (kt + DIST < KT) issue(nbuf);
+        const char* sA = smem + buf * STAGE_BYTES;
+        mma_slab<T, BKB>(sA, sA + TILE_BYTES, wave_c, wave_p, lane, acc);
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+        nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
+    }
+
+    T* out = reinterpret_cast<T*>(P.out);
+    const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = p_base + wave_p * 64 + j * 16 + r16;
+        if (p >= P.M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
+            if (co >= P.NO) continue;
+            f32x4 v = acc[i][j];
+            if (P.bias) {
+                v[0] += P.bias[co + 0];
+                v[1] += P.bias[co + 1];
+                v[2] += P.bias[co + 2];
+                v[3] += P.bias[co + 3];
+            }
+            T* dst = out + p * P.ldo + co;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 o;
+                o[0] = (bf16_t)v[0];
+                o[1] = (bf16_t)v[1];
+                o[2] = (bf16_t)v[2];
+                o[3] = (bf16_t)v[3];
+                *reinterpret_cast<bf16x4*>(dst) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad ----
 struct WgradParams {
     const void* x;
@@ -291,6 +473,7 @@ struct WgradParams {
     long long M;
     long long pix_per_split;  // multiple of 32
     int tiles_co, tiles_ci;
+    int x_bytes, dy_bytes;    // exact operand extents (buffer-load range check)
 };
 
 constexpr int WG_PIX = 32;  // pixels per K-chunk
@@ -392,39 +575,56 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     if (p_begin >= p_end) return;  // uniform per block
 
     const int chunk = tid % CPR, row0 = tid / CPR;
+    constexpr int ES = (int)sizeof(T);
     const bool co_ok = co_base + chunk * VEC < P.Co;
     const bool ci_ok = ci_base + chunk * VEC < P.Ci;
-    const T* x = reinterpret_cast<const T*>(P.x);
-    const T* dy = reinterpret_cast<const T*>(P.dy);
     const int ohw = P.Ho * P.Wo;
-    const bool pointwise = RS == 1 && P.stride == 1 && P.pad == 0;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.x), 0, P.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.dy), 0, P.dy_bytes, 0x00020000);
+
+    // Per-thread row cursors, advanced by WG_PIX pixels per chunk with adds only (the
+    // (n, oh, ow) decomposition of the first pixel is the only division in the kernel).
+    int row_p[NPASS];           // pixel index relative to p_begin
+    int off_dy[NPASS];          // byte offset of dy[p, co_base + chunk]
+    int r_n[NPASS], r_oh[NPASS], r_ow[NPASS];
+    const int span = (int)(p_end - p_begin);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        row_p[i] = row0 + i * RPP;
+        const unsigned pu = (unsigned)(p_begin + row_p[i]);
+        off_dy[i] = (int)(pu * (unsigned)P.ldy + (unsigned)(co_base + chunk * VEC)) * ES;
+        const unsigned n = pu / (unsigned)ohw;
+        const unsigned rem = pu - n * (unsigned)ohw;
+        const unsigned q = rem / (unsigned)P.Wo;
+        r_n[i] = (int)n;
+        r_oh[i] = (int)q;
+        r_ow[i] = (int)(rem - q * (unsigned)P.Wo);
+    }
+    const int dy_step = WG_PIX * P.ldy * ES;
 
     Chunk<T> ra[NPASS], rb[NPASS];
-    auto issue_loads = [&](long long pc) {
+    auto issue_loads = [&]() {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const long long p = pc + row0 + i * RPP;
-            const bool pv = p < p_end;
-            if (pv && co_ok) ra[i].load(dy + p * P.ldy + co_base + chunk * VEC);
-            else ra[i].zero();
-            bool ok = pv && ci_ok;
-            long long off = 0;
-            if (ok) {
-                if (pointwise) {  // 1x1, stride 1, no padding: input pixel == output pixel
-                    off = p * P.ldx + ci_base + chunk * VEC;
-                } else {
-                    const unsigned pu = (unsigned)p;  // M < 2^31 (checked on the host)
-                    const unsigned n = pu / (unsigned)ohw;
-                    const unsigned rem = pu - n * (unsigned)ohw;
-                    const int oh = (int)(rem / (unsigned)P.Wo), ow = (int)(rem - (rem / (unsigned)P.Wo) * (unsigned)P.Wo);
-                    const int ih = oh * P.stride - P.pad + r * P.dil;
-                    const int iw = ow * P.stride - P.pad + s * P.dil;
-                    ok = (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W;
-                    off = (((long long)n * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC;
-                }
+            const bool pv = row_p[i] < span;
+            ra[i].v = __builtin_bit_cast(typename Elem<T>::vec_t,
+                                         __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (pv && co_ok) ? off_dy[i] : OOB, 0, 0));
+            int ox = OOB;
+            if (pv && ci_ok) {
+                const int ih = r_oh[i] * P.stride - P.pad + r * P.dil;
+                const int iw = r_ow[i] * P.stride - P.pad + s * P.dil;
+                if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
+                    ox = (((r_n[i] * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC) * ES;
             }
-            if (ok) rb[i].load(x + off);
-            else rb[i].zero();
+            rb[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ox, 0, 0));
+            // advance this row's cursor to the next chunk
+            row_p[i] += WG_PIX;
+            off_dy[i] += dy_step;
+            r_ow[i] += WG_PIX;
+            while (r_ow[i] >= P.Wo) {
+                r_ow[i] -= P.Wo;
+                if (++r_oh[i] == P.Ho) { r_oh[i] = 0; ++r_n[i]; }
+            }
         }
     };
     auto write_lds = [&](int buf) {
@@ -446,13 +646,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    issue_loads(p_begin);
+    issue_loads();
     write_lds(0);
     __syncthreads();
     int cur = 0;
     for (long long pc = p_begin; pc < p_end; pc += WG_PIX) {
         const bool more = pc + WG_PIX < p_end;
-        if (more) issue_loads(pc + WG_PIX);
+        if (more) issue_loads();
         const char* sA = smem + cur * 2 * TILE_BYTES;
         wgrad_mma<T>(sA, sA + TILE_BYTES, wave_m, wave_n, lane, acc);
         if (more) write_lds(cur ^ 1);
@@ -555,6 +755,23 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     const int pad64 = (P.CK + bk64 - 1) / bk64 * bk64, pad128 = (P.CK + bk128 - 1) / bk128 * bk128;
     bool use128 = pad128 <= pad64 + pad64 / 32;
     if (const char* e = getenv("BGAMD_BKB")) use128 = atoi(e) == 128;  // tuning knob
+    static const int dma_mode = getenv("BGAMD_DMA") ? atoi(getenv("BGAMD_DMA")) : 1;  // 0: register staging; 1: 3-stage ring, 64-byte rows (default); 2: 128-byte rows where they pad less; 3: 4-stage ring
+    if (dma_mode) {
+        if (use128 && dma_mode == 2) {
+            const size_t sh = 3 * 2 * TILE * 128;  // 96 KiB
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 128, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 128, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+        } else if (dma_mode == 3) {
+            const size_t sh = 4 * 2 * TILE * 64;  // 64 KiB
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 4>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+        } else {
+            const size_t sh = 3 * 2 * TILE * 64;  // 48 KiB
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+        }
+        BG_CHECK_LAUNCH("gemm_conv_dma_kernel");
+        return BG_OK;
+    }
     if (use128) {
         const size_t sh = 2 * 2 * TILE * 128;
         hipLaunchKernelGGL((gemm_conv_kernel<T, 128>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
@@ -626,6 +843,14 @@ extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const 
     P.pix_per_split = ((P.M + splits - 1) / splits + WG_PIX - 1) / WG_PIX * WG_PIX;
     splits = (P.M + P.pix_per_split - 1) / P.pix_per_split;
     BG_CHECK_ARG(tiles * splits <= 0x7fffffffLL, "bg_conv2d_bwd_weight: grid too large");
+    {
+        const long long es = dtype_size(d->dtype);
+        const long long xb = (((long long)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * es;
+        const long long yb = ((P.M - 1) * d->ldy + d->Cout) * es;
+        BG_CHECK_ARG(xb < (1LL << 31) && yb < (1LL << 31), "bg_conv2d_bwd_weight: operand larger than 2 GiB");
+        P.x_bytes = (int)xb;
+        P.dy_bytes = (int)yb;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == BG_BF16) {
         const size_t sh = 2 * 2 * WG_PIX * (TILE * 2 + 64);
