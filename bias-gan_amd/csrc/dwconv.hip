@@ -13,7 +13,22 @@ struct DwParams {
     void* y;
     int N, H, W, C, Ho, Wo, stride, dil, ldx, ldy;
     int items;  // Wo*(C/VEC) (fwd) or W*(C/VEC) (bwd_data): work items of one image row
+    int bx;     // 256-thread blocks per image row; the grid is 1-D: rows * bx blocks
 };
+
+// 1-D grid -> (image row, block inside the row).  Blocks with the same id % 8 share an
+// XCD and its L2; give every XCD a CONTIGUOUS band of rows, so the three output rows
+// that read one input row find it in the same L2 (with the hardware's round-robin
+// order every input row was fetched from HBM by three different XCDs: measured
+// 3.2x the algorithmic read traffic).
+__device__ __forceinline__ void dw_block_to_row(int bx, int& row, int& xblk) {
+    const int nblk = gridDim.x;
+    int lin = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = lin & 7, k = lin >> 3;
+    lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    row = lin / bx;
+    xblk = lin - row * bx;
+}
 
 // grid: y = (n, output row), x = 256-thread blocks over (wo, channel vector) with
 // the channel vector fastest.  One 32-bit division per thread, none per tap.
@@ -21,11 +36,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwParams P) {
     constexpr int VEC = Elem<T>::VEC;
     const unsigned cv = P.C / VEC;
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    int grow, xblk;
+    dw_block_to_row(P.bx, grow, xblk);
+    const unsigned idx = xblk * 256u + threadIdx.x;
     if (idx >= (unsigned)P.items) return;
     const unsigned wo = idx / cv;
     const int c = (int)(idx - wo * cv) * VEC;
-    const int n = blockIdx.y / P.Ho, ho = blockIdx.y - n * P.Ho;
+    const int n = grow / P.Ho, ho = grow - n * P.Ho;
     const T* x = reinterpret_cast<const T*>(P.x) + (long long)n * P.H * P.W * P.ldx + c;
     const T* w = reinterpret_cast<const T*>(P.w) + c;
     float acc[VEC];
@@ -62,12 +79,14 @@ __global__ __launch_bounds__(256) void dw_fwd_tw_kernel(DwParams P) {
     constexpr int TW = 4;
     constexpr int NCOL = (TW - 1) * S + 2 * D + 1;
     const unsigned cv = P.C / VEC;
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    int grow, xblk;
+    dw_block_to_row(P.bx, grow, xblk);
+    const unsigned idx = xblk * 256u + threadIdx.x;
     if (idx >= (unsigned)P.items) return;
     const unsigned wq = idx / cv;
     const int c = (int)(idx - wq * cv) * VEC;
     const int wo0 = (int)wq * TW;
-    const int n = blockIdx.y / P.Ho, ho = blockIdx.y - n * P.Ho;
+    const int n = grow / P.Ho, ho = grow - n * P.Ho;
     const T* x = reinterpret_cast<const T*>(P.x) + (long long)n * P.H * P.W * P.ldx + c;
     const T* w = reinterpret_cast<const T*>(P.w) + c;
     float acc[TW][VEC];
@@ -116,11 +135,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwParams P) {
     constexpr int VEC = Elem<T>::VEC;
     const unsigned cv = P.C / VEC;
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    int grow, xblk;
+    dw_block_to_row(P.bx, grow, xblk);
+    const unsigned idx = xblk * 256u + threadIdx.x;
     if (idx >= (unsigned)P.items) return;
     const unsigned iw = idx / cv;
     const int c = (int)(idx - iw * cv) * VEC;
-    const int n = blockIdx.y / P.H, ih = blockIdx.y - n * P.H;
+    const int n = grow / P.H, ih = grow - n * P.H;
     const T* dy = reinterpret_cast<const T*>(P.x) + (long long)n * P.Ho * P.Wo * P.ldy + c;
     const T* w = reinterpret_cast<const T*>(P.w) + c;
     float acc[VEC];
@@ -285,21 +306,24 @@ extern "C" int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const vo
     int rc = check_dw(d, "bg_dwconv3x3_fwd");
     if (rc) return rc;
     BG_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "bg_dwconv3x3_fwd: null/unaligned pointer");
-    DwParams P{x, w, y, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0};
+    DwParams P{x, w, y, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0, 0};
     const long long rows = (long long)d->N * d->Ho;
-    BG_CHECK_ARG(rows <= 65535, "bg_dwconv3x3_fwd: N*Ho too large");
     hipStream_t st = (hipStream_t)stream;
     const int cv = d->C / dtype_vec(d->dtype);
     const int sd = d->stride * 10 + d->dil;
     if (sd == 11 || sd == 12 || sd == 21) {
         P.items = ((d->Wo + 3) / 4) * cv;
-        dim3 grid((P.items + 255) / 256, (unsigned)rows);
+        P.bx = (P.items + 255) / 256;
+        BG_CHECK_ARG(rows * P.bx <= 0x7fffffffLL, "bg_dwconv3x3_fwd: grid too large");
+        dim3 grid((unsigned)(rows * P.bx));
         if (sd == 11) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 1, 0>), grid, dim3(256), 0, st, P));
         else if (sd == 12) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 2, 0>), grid, dim3(256), 0, st, P));
         else BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 2, 1, 0>), grid, dim3(256), 0, st, P));
     } else {
         P.items = d->Wo * cv;
-        dim3 grid((P.items + 255) / 256, (unsigned)rows);
+        P.bx = (P.items + 255) / 256;
+        BG_CHECK_ARG(rows * P.bx <= 0x7fffffffLL, "bg_dwconv3x3_fwd: grid too large");
+        dim3 grid((unsigned)(rows * P.bx));
         BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_kernel<T>), grid, dim3(256), 0, st, P));
     }
     BG_CHECK_LAUNCH("dw_fwd_kernel");
@@ -311,24 +335,27 @@ extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, co
     if (rc) return rc;
     BG_CHECK_ARG(dy && w && dx && aligned16(dy) && aligned16(w) && aligned16(dx),
                  "bg_dwconv3x3_bwd_data: null/unaligned pointer");
-    DwParams P{dy, w, dx, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0};
+    DwParams P{dy, w, dx, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0, 0};
     const long long rows = (long long)d->N * d->H;
-    BG_CHECK_ARG(rows <= 65535, "bg_dwconv3x3_bwd_data: N*H too large");
     hipStream_t st = (hipStream_t)stream;
     const int cv = d->C / dtype_vec(d->dtype);
     if (d->stride == 1 && (d->dil == 1 || d->dil == 2)) {
         // stride 1: the data gradient is the same stencil with the taps reversed
         // (dy plays the input, dx the output; both are H x W)
-        DwParams Q{dy, w, dx, d->N, d->H, d->W, d->C, d->H, d->W, 1, d->dil, d->ldy, d->ldx, 0};
+        DwParams Q{dy, w, dx, d->N, d->H, d->W, d->C, d->H, d->W, 1, d->dil, d->ldy, d->ldx, 0, 0};
         Q.items = ((d->W + 3) / 4) * cv;
-        dim3 grid((Q.items + 255) / 256, (unsigned)rows);
+        Q.bx = (Q.items + 255) / 256;
+        BG_CHECK_ARG(rows * Q.bx <= 0x7fffffffLL, "bg_dwconv3x3_bwd_data: grid too large");
+        dim3 grid((unsigned)(rows * Q.bx));
         if (d->dil == 1) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 1, 1>), grid, dim3(256), 0, st, Q));
         else BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 2, 1>), grid, dim3(256), 0, st, Q));
         BG_CHECK_LAUNCH("dw_fwd_tw_kernel(flip)");
         return BG_OK;
     }
     P.items = d->W * cv;
-    dim3 grid((P.items + 255) / 256, (unsigned)rows);
+    P.bx = (P.items + 255) / 256;
+    BG_CHECK_ARG(rows * P.bx <= 0x7fffffffLL, "bg_dwconv3x3_bwd_data: grid too large");
+    dim3 grid((unsigned)(rows * P.bx));
     BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_bwd_data_kernel<T>), grid, dim3(256), 0, st, P));
     BG_CHECK_LAUNCH("dw_bwd_data_kernel");
     return BG_OK;
