@@ -31,6 +31,7 @@ class DwDesc(C.Structure):
 _SIGS = {
     "bg_abi_version": [],
     "bg_conv2d_fwd": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bg_conv2d_fwd_stats": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_data": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_pack_conv_weights": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],

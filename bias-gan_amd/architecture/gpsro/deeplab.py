@@ -75,14 +75,15 @@ class Conv2d(BGModule):
             nn.init.uniform_(self.bias, -bound, bound)
         self._bg_param_layout = {"weight": _dw_layout if groups > 1 else _conv_layout, "bias": _vec_layout}
 
-    def forward(self, x):
-        """x: NHWC activation (padded channels)."""
+    def forward(self, x, stats=None):
+        """x: NHWC activation (padded channels).  stats: see ops.Conv2dFn."""
         a = self.arena()
         ws = a.by_param[id(self.weight)]
         if self.groups > 1:
             return ops.DwConv3x3Fn.apply(x, self.weight, a, ws, self.stride[0], self.dilation[0])
         bs = None if self.bias is None else a.by_param[id(self.bias)]
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, bs, self.stride[0], self.padding[0], self.dilation[0])
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, bs, self.stride[0], self.padding[0], self.dilation[0],
+                                  stats)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size[0]}, s={self.stride[0]}, groups={self.groups}"
@@ -103,7 +104,24 @@ def _norm_kind(m: nn.Module) -> str:
                               "(BatchNorm2d, InstanceNorm2d and Identity are)")
 
 
-def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False):
+import os as _os
+_FUSED_STATS = _os.environ.get("BGAMD_NO_FUSED_STATS") is None  # A/B switch
+
+
+def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
+    """conv (Conv2d or SeparableConv2d_same) -> norm (+ residual) (+ LeakyReLU).  When the
+    normaliser is a training-mode BatchNorm2d its batch statistics come out of the
+    convolution's epilogue instead of a separate pass over the conv output."""
+    dense = conv.pointwise if isinstance(conv, SeparableConv2d_same) else conv
+    stats = None
+    if isinstance(m, nn.BatchNorm2d) and m.training and dense.bias is None and _FUSED_STATS:
+        kp = owner.arena().by_param[id(dense.weight)].phys_shape[0]
+        stats = torch.zeros((2, kp), dtype=torch.float64, device=x.device)
+    y = conv(x, stats) if stats is not None else conv(x)
+    return apply_norm(owner, m, y, res=res, act=act, stats=stats)
+
+
+def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False, stats=None):
     """norm (+ residual) (+ LeakyReLU(0.2)) in one pass over the activation."""
     kind = _norm_kind(m)
     if kind == "identity":
@@ -121,7 +139,7 @@ def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False):
         m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + 1
     mom = 0.1 if m.momentum is None else float(m.momentum)
     return ops.NormActFn.apply(x, res, m.weight, m.bias, a, gs, bs, m.running_mean, m.running_var, "batch", m.training,
-                               act, float(m.eps), mom)
+                               act, float(m.eps), mom, stats)
 
 
 def fixed_padding_extents(kernel_size, rate):
@@ -141,8 +159,8 @@ class SeparableConv2d_same(BGModule):
         self.conv1 = Conv2d(inplanes, inplanes, kernel_size, stride, 0, dilation, groups=inplanes, bias=bias)
         self.pointwise = Conv2d(inplanes, planes, 1, 1, 0, 1, 1, bias=bias)
 
-    def forward(self, x):
-        return self.pointwise(self.conv1(x))
+    def forward(self, x, stats=None):
+        return self.pointwise(self.conv1(x), stats)
 
 
 class Block(BGModule):
@@ -187,27 +205,34 @@ class Block(BGModule):
         i = 1 if self.start_with_relu else 0
         h = a_main
         last_norm = None
+        last_sep = None
         while i < len(units):
             u = units[i]
             if isinstance(u, SeparableConv2d_same):
-                h = u(h)
-                i += 1
+                nxt_norm = i + 1 < len(units) and not isinstance(units[i + 1], (SeparableConv2d_same, nn.LeakyReLU))
+                if not nxt_norm:
+                    h = u(h)
+                    i += 1
+                    continue
+                m = units[i + 1]
+                if i + 1 == len(units) - 1:      # block-final norm: fused with the residual below
+                    last_norm, last_sep = m, u
+                    break
+                nxt_relu = isinstance(units[i + 2], nn.LeakyReLU)
+                h = conv_norm(self, u, m, h, act=nxt_relu)
+                i += 3 if nxt_relu else 2
             elif isinstance(u, nn.LeakyReLU):
                 h = ops.leaky_relu(h)
                 i += 1
-            else:
-                if i == len(units) - 1:
-                    last_norm = u
-                    break
-                nxt_relu = isinstance(units[i + 1], nn.LeakyReLU)
-                h = apply_norm(self, u, h, act=nxt_relu)
-                i += 2 if nxt_relu else 1
+            else:  # a norm not preceded by a conv (not produced by the reference's constructor)
+                h = apply_norm(self, u, h)
+                i += 1
         if self.skip is not None:
-            s = apply_norm(self, self.skipbn, self.skip(a_skip))
+            s = conv_norm(self, self.skip, self.skipbn, a_skip)
         else:
             s = a_skip
         if last_norm is not None:
-            return apply_norm(self, last_norm, h, res=s, act=activate_output)
+            return conv_norm(self, last_sep, last_norm, h, res=s, act=activate_output)
         return ops.add(h, s, act=activate_output)
 
 
@@ -258,8 +283,8 @@ class Xception(BGModule):
                 nn.init.zeros_(m.bias)
 
     def forward_nhwc(self, x, want_low=True):
-        x = apply_norm(self, self.bn1, self.conv1(x), act=True)
-        x = apply_norm(self, self.bn2, self.conv2(x), act=True)
+        x = conv_norm(self, self.conv1, self.bn1, x, act=True)
+        x = conv_norm(self, self.conv2, self.bn2, x, act=True)
         # every block output below already carries the next block's leading LeakyReLU
         x = self.block1(x, activate_output=True)
         low = None
@@ -269,9 +294,9 @@ class Xception(BGModule):
         for i in range(2, 20):
             x = getattr(self, f"block{i}")(x, pre_activated=True, activate_output=True)
         x = self.block20(x, pre_activated=True, activate_output=False)
-        x = apply_norm(self, self.bn3, self.conv3(x), act=True)
-        x = apply_norm(self, self.bn4, self.conv4(x), act=True)
-        x = apply_norm(self, self.bn5, self.conv5(x), act=True)
+        x = conv_norm(self, self.conv3, self.bn3, x, act=True)
+        x = conv_norm(self, self.conv4, self.bn4, x, act=True)
+        x = conv_norm(self, self.conv5, self.bn5, x, act=True)
         return x, low
 
     def forward(self, x):
@@ -294,7 +319,7 @@ class ASPP_module(BGModule):
         nn.init.kaiming_normal_(self.atrous_convolution.weight)
 
     def forward(self, x):
-        return apply_norm(self, self.bn, self.atrous_convolution(x), act=True)
+        return conv_norm(self, self.atrous_convolution, self.bn, x, act=True)
 
 
 def _gan_conv_init(m: Conv2d):
@@ -324,8 +349,8 @@ class InterpolationUpsampler(BGModule):
         x = ops.ResizeBilinearFn.apply(x, -(-H // 4), -(-W // 4), None)
         x = ops.concat(x, low_level_features)
         lc = self.last_conv
-        x = apply_norm(self, lc[1], lc[0](x), act=True)
-        x = apply_norm(self, lc[4], lc[3](x), act=True)
+        x = conv_norm(self, lc[0], lc[1], x, act=True)
+        x = conv_norm(self, lc[3], lc[4], x, act=True)
         x = lc[6](x)
         # final resize writes fp32: it is the generator output / loss input
         return ops.ResizeBilinearFn.apply(x, H, W, torch.float32)
@@ -376,11 +401,11 @@ class DeepLabv3_plus(BGModule):
         x1i, x2i, x3i, x4i, x5i = ops.fork(x, 5)
         x1, x2, x3, x4 = self.aspp1(x1i), self.aspp2(x2i), self.aspp3(x3i), self.aspp4(x4i)
         gp = self.global_avg_pool
-        x5 = apply_norm(self, gp[2], gp[1](ops.GlobalAvgPoolFn.apply(x5i)), act=True)
+        x5 = conv_norm(self, gp[1], gp[2], ops.GlobalAvgPoolFn.apply(x5i), act=True)
         x5 = ops.ResizeBilinearFn.apply(x5, x4.shape[1], x4.shape[2], None)
         x = ops.concat(x1, x2, x3, x4, x5)
-        x = apply_norm(self, self.bn1, self.conv1(x), act=True)
-        low = apply_norm(self, self.bn2, self.conv2(low), act=True)
+        x = conv_norm(self, self.conv1, self.bn1, x, act=True)
+        low = conv_norm(self, self.conv2, self.bn2, low, act=True)
         return self.upsample(x, low, (H, W))
 
     def forward(self, input):

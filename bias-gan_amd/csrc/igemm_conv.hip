@@ -45,6 +45,8 @@ struct GemmConvParams {
     int transposed;
     long long M;  // N*OH*OW
     int tiles_c, tiles_p;
+    double* stat_sum;  // optional per-output-channel sum / sum of squares of the STORED outputs
+    double* stat_sq;   // (BatchNorm statistics fused into the epilogue); NULL = off
     int CKp;       // K stride of one tap inside the (zero-padded) weight copy
     int in_bytes;  // exact extent of the activation operand (buffer-load range check)
     int w_bytes;
@@ -95,6 +97,95 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wav
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// Epilogue shared by both staging variants.  A lane holds, per accumulator, 4
+// consecutive output channels of one pixel -> 8/16-byte NHWC stores.  With
+// P.stat_sum set it also reduces sum(y) and sum(y^2) of the values AS STORED
+// (after rounding to T) over the tile's 128 pixels: 16-lane shuffle tree, the two
+// pixel-waves are combined through LDS, one fp64 atomic per channel per tile.
+template <typename T>
+__device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&acc)[4][4], long long p_base, int c_base,
+                                              int wave_c, int wave_p, int lane, char* smem) {
+    T* out = reinterpret_cast<T*>(P.out);
+    const int r16 = lane & 15, q = lane >> 4;
+    float s1[4][4], s2[4][4];
+    if (P.stat_sum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = p_base + wave_p * 64 + j * 16 + r16;
+        const bool p_ok = p < P.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
+            if (co >= P.NO) continue;
+            f32x4 v = acc[i][j];
+            if (P.bias) {
+                v[0] += P.bias[co + 0];
+                v[1] += P.bias[co + 1];
+                v[2] += P.bias[co + 2];
+                v[3] += P.bias[co + 3];
+            }
+            T o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(v[e]);
+            if (P.stat_sum && p_ok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = Elem<T>::to_f(o[e]);
+                    s1[i][e] += r;
+                    s2[i][e] = fmaf(r, r, s2[i][e]);
+                }
+            }
+            if (!p_ok) continue;
+            T* dst = out + p * P.ldo + co;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 ov = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<bf16x4*>(dst) = ov;
+            } else {
+                f32x4 ov = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(dst) = ov;
+            }
+        }
+    }
+    if (P.stat_sum) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = s1[i][e], b = s2[i][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                s1[i][e] = a;
+                s2[i][e] = b;
+            }
+        __syncthreads();  // every wave is done reading the staging ring: reuse it
+        float* red = reinterpret_cast<float*>(smem);  // [wave_p][128 channels][2]
+        if (r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cl = wave_c * 64 + i * 16 + q * 4 + e;
+                    red[(wave_p * TILE + cl) * 2 + 0] = s1[i][e];
+                    red[(wave_p * TILE + cl) * 2 + 1] = s2[i][e];
+                }
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < TILE && c_base + t < P.NO) {
+            atomicAdd(P.stat_sum + c_base + t, (double)(red[t * 2] + red[(TILE + t) * 2]));
+            atomicAdd(P.stat_sq + c_base + t, (double)(red[t * 2 + 1] + red[(TILE + t) * 2 + 1]));
         }
     }
 }
@@ -246,37 +337,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
         cur ^= 1;
     }
 
-    // epilogue: lane holds 4 consecutive out-channels of one pixel per accumulator
-    T* out = reinterpret_cast<T*>(P.out);
-    const int r16 = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long p = p_base + wave_p * 64 + j * 16 + r16;
-        if (p >= P.M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
-            if (co >= P.NO) continue;
-            f32x4 v = acc[i][j];
-            if (P.bias) {
-                v[0] += P.bias[co + 0];
-                v[1] += P.bias[co + 1];
-                v[2] += P.bias[co + 2];
-                v[3] += P.bias[co + 3];
-            }
-            T* dst = out + p * P.ldo + co;
-            if constexpr (sizeof(T) == 2) {
-                bf16x4 o;
-                o[0] = (bf16_t)v[0];
-                o[1] = (bf16_t)v[1];
-                o[2] = (bf16_t)v[2];
-                o[3] = (bf16_t)v[3];
-                *reinterpret_cast<bf16x4*>(dst) = o;
-            } else {
-                *reinterpret_cast<f32x4*>(dst) = v;
-            }
-        }
-    }
+    conv_epilogue<T>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
 }
 
 // ------------------------------------------------------- LDS-DMA variant ----
@@ -429,36 +490,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
         nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
     }
 
-    T* out = reinterpret_cast<T*>(P.out);
-    const int r16 = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long p = p_base + wave_p * 64 + j * 16 + r16;
-        if (p >= P.M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = c_base + wave_c * 64 + i * 16 + q * 4;
-            if (co >= P.NO) continue;
-            f32x4 v = acc[i][j];
-            if (P.bias) {
-                v[0] += P.bias[co + 0];
-                v[1] += P.bias[co + 1];
-                v[2] += P.bias[co + 2];
-                v[3] += P.bias[co + 3];
-            }
-            T* dst = out + p * P.ldo + co;
-            if constexpr (sizeof(T) == 2) {
-                bf16x4 o;
-                o[0] = (bf16_t)v[0];
-                o[1] = (bf16_t)v[1];
-                o[2] = (bf16_t)v[2];
-                o[3] = (bf16_t)v[3];
-                *reinterpret_cast<bf16x4*>(dst) = o;
-            } else {
-                *reinterpret_cast<f32x4*>(dst) = v;
-            }
-        }
-    }
+    conv_epilogue<T>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
 }
 
 // ------------------------------------------------------------------ wgrad ----
@@ -797,6 +829,24 @@ extern "C" int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
     P.transposed = 0;
     P.M = (long long)d->N * d->Ho * d->Wo;
+    if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
+    return launch_gemm_conv<float>(P, (hipStream_t)stream);
+}
+
+extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum,
+                                   double* sumsq, void* stream) {
+    int rc = check_conv_desc(d, "bg_conv2d_fwd_stats");
+    if (rc) return rc;
+    BG_CHECK_ARG(x && w && y && sum && sumsq && aligned16(x) && aligned16(w) && aligned16(y),
+                 "bg_conv2d_fwd_stats: null/unaligned pointer");
+    GemmConvParams P{};
+    P.in = x; P.w = w; P.out = y; P.bias = nullptr;
+    P.N = d->N; P.IH = d->H; P.IW = d->W; P.OH = d->Ho; P.OW = d->Wo;
+    P.CK = d->Cin; P.NO = d->Cout; P.ldi = d->ldx; P.ldo = d->ldy;
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
+    P.transposed = 0;
+    P.M = (long long)d->N * d->Ho * d->Wo;
+    P.stat_sum = sum; P.stat_sq = sumsq;
     if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
     return launch_gemm_conv<float>(P, (hipStream_t)stream);
 }

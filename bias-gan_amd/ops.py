@@ -132,7 +132,10 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d(groups=1) as implicit GEMM (bg_conv2d_*)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, arena: Arena, wslot: ParamSlot, bslot: Optional[ParamSlot], stride, pad, dil):
+    def forward(ctx, x, weight, bias, arena: Arena, wslot: ParamSlot, bslot: Optional[ParamSlot], stride, pad, dil,
+                stats=None):
+        """stats: optional zeroed fp64 [2, Cout_phys]; the kernel adds sum(y), sum(y^2) of the stored
+        outputs to it from its accumulators (the batch statistics of the BatchNorm that follows)."""
         x = nhwc(x)
         n, h, w, cin = x.shape
         kp, kh, kw, cp = wslot.phys_shape
@@ -141,8 +144,13 @@ class Conv2dFn(torch.autograd.Function):
         wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), kp)
-        L.call("bg_conv2d_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot),
-               None if bslot is None else arena.master_ptr(bslot), y.data_ptr())
+        if stats is not None:
+            assert bslot is None and stats.shape == (2, kp) and stats.dtype == torch.float64
+            L.call("bg_conv2d_fwd_stats", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr(), stats[0].data_ptr(),
+                   stats[1].data_ptr())
+        else:
+            L.call("bg_conv2d_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot),
+                   None if bslot is None else arena.master_ptr(bslot), y.data_ptr())
         # the input is only needed for the weight gradient: do not keep it alive otherwise
         # (G-step: the discriminator is differentiated w.r.t. its input only)
         if weight.requires_grad:
@@ -170,7 +178,7 @@ class Conv2dFn(torch.autograd.Function):
                 arena.ensure_grad(bslot)
                 dbias = arena.grad_ptr(bslot)
             L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
-        return dx, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None
 
 
 class DwConv3x3Fn(torch.autograd.Function):
@@ -218,7 +226,10 @@ class NormActFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum):
+    def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum,
+                pre_stats=None):
+        """pre_stats: fp64 [2, C] sums already produced by the convolution's epilogue
+        (bg_conv2d_fwd_stats); skips the separate statistics pass."""
         x = nhwc(x)
         n, h, w, c = x.shape
         dev, dt = x.device, L.dt(x.dtype)
@@ -233,8 +244,11 @@ class NormActFn(torch.autograd.Function):
             gptr = None if gslot is None else arena.master_ptr(gslot)
             bptr = None if bslot is None else arena.master_ptr(bslot)
             if use_batch_stats:
-                s = _f64(2, groups, c, device=dev)
-                L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
+                if pre_stats is not None and groups == 1:
+                    s = pre_stats.view(2, 1, c)
+                else:
+                    s = _f64(2, groups, c, device=dev)
+                    L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
                 upd = kind == "batch" and rmean is not None
                 L.call("bg_norm_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, bptr, eps,
                        momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
@@ -265,12 +279,12 @@ class NormActFn(torch.autograd.Function):
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
         if kind == "identity":
             if dx is None and dres is None:
-                return (None,) * 14
+                return (None,) * 15
             # dx and dres are the same tensor values: write once, alias
             out = dx if dx is not None else dres
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None,
                    out.data_ptr(), c, None, 0, rows, c, groups, act)
-            return (out if need_dx else None, out if need_res else None) + (None,) * 12
+            return (out if need_dx else None, out if need_res else None) + (None,) * 13
         want_affine_grads = gslot is not None and gslot.param.requires_grad
         if need_dx or want_affine_grads:
             s = _f64(2, groups, c, device=dev)
@@ -292,7 +306,7 @@ class NormActFn(torch.autograd.Function):
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None, None, 0,
                    dres.data_ptr(), c, rows, c, groups, act)
-        return (dx, dres) + (None,) * 12
+        return (dx, dres) + (None,) * 13
 
 
 def leaky_relu(x):

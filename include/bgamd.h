@@ -74,6 +74,11 @@ typedef struct bg_conv_desc {
 
 /* y = conv(x, w) (+ bias[Cout], fp32, may be NULL).  w: K-padded KRSC copy, dtype = d->dtype. */
 int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
+/* Same as bg_conv2d_fwd without bias, and additionally sum[c] += sum_pixels y, sumsq[c] += sum_pixels y^2
+ * of the outputs as stored (fp64 [Cout], caller zeroes): the batch statistics of the BatchNorm that
+ * follows the convolution, taken from the accumulators instead of re-reading y (replaces bg_norm_stats). */
+int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum, double* sumsq,
+                        void* stream);
 /* dx = conv_transpose(dy, w).  wt: K-padded CRSK copy of the weights.  Overwrites dx. */
 int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
 /* dw += x (*) dy, dw fp32 KRSC (accumulated with float atomics; caller zeroes it

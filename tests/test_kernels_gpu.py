@@ -450,3 +450,21 @@ def test_bad_arguments_raise():
     d = L.ConvDesc(L.BF16, 1, 8, 8, 16, 9, 8, 16, 1, 1, 1, 0, 1, 16, 16)  # wrong Ho
     with pytest.raises(RuntimeError, match="conv arithmetic"):
         L.call("bg_conv2d_fwd", d, z.data_ptr(), z.data_ptr(), None, z.data_ptr())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fwd_fused_statistics(dtype):
+    """bg_conv2d_fwd_stats: per-channel sum / sum of squares of the STORED outputs from the epilogue."""
+    n, h, w, cin, cout, k = 3, 13, 11, 24, 200, 3
+    x = rnd((n, cin, h, w), 21, dtype)
+    wt = rnd((cout, cin, k, k), 22, dtype, 1.0 / math.sqrt(cin * k * k))
+    desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, k, 1, 1, 1, up(cin, dtype), up(cout, dtype))
+    xb, xv = to_nhwc(x, dtype)
+    wpk, _ = pack(krsc(wt, dtype), dtype)
+    yb = torch.zeros(n, ho, wo, up(cout, dtype), dtype=dtype, device=DEV)
+    st = torch.zeros(2, up(cout, dtype), dtype=torch.float64, device=DEV)
+    L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr())
+    y = yb.double()
+    assert_close(from_nhwc(yb, cout), F.conv2d(x, wt, None, 1, 1, 1), tol(dtype), "fwd")
+    assert_close(st[0].cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
+    assert_close(st[1].cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
