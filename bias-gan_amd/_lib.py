@@ -27,6 +27,22 @@ class DwDesc(C.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "N", "H", "W", "C", "Ho", "Wo", "stride", "dil", "ldx", "ldy")]
 
 
+class NpyInfo(C.Structure):
+    _fields_ = [("dtype_code", c_i32), ("typesize", c_i32), ("fortran_order", c_i32), ("ndim", c_i32),
+                ("shape", c_i64 * 8), ("data_offset", c_i64), ("file_size", c_i64)]
+
+
+# host-side entry points (no stream argument): name -> argtypes
+_HOST_SIGS = {
+    "bg_npy_parse": [C.c_char_p, C.POINTER(NpyInfo)],
+    "bg_ring_create": [c_i32, c_i32, c_i64, c_i32, C.POINTER(c_vp)],
+    "bg_ring_destroy": [c_vp],
+    "bg_ring_submit": [c_vp, C.c_char_p, c_i64, c_i64, c_i32, C.POINTER(c_i64)],
+    "bg_ring_acquire": [c_vp, c_i64, c_vp, C.POINTER(c_vp)],
+    "bg_ring_copy_out": [c_vp, c_i64, c_vp, c_i64, c_vp],
+    "bg_ring_release": [c_vp, c_i64, c_vp],
+}
+
 # name -> argtypes (restype is int for all but bg_last_error); mirrors include/bgamd.h
 _SIGS = {
     "bg_abi_version": [],
@@ -68,7 +84,7 @@ _SIGS = {
                      c_f32, c_vp],
     "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["bg_last_error", "bg_conv_weight_kpad"])
+EXPORTS = sorted(list(_SIGS) + list(_HOST_SIGS) + ["bg_last_error", "bg_conv_weight_kpad"])
 
 _lib = None
 
@@ -84,6 +100,10 @@ def load():
             "(hipcc --offload-arch=gfx950). There is no PyTorch/CPU fallback for the hot path.")
     lib = C.CDLL(LIB_PATH)
     for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_i32
+    for name, args in _HOST_SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = c_i32
@@ -127,6 +147,19 @@ PROFILE = None
 
 def _conv_flops(desc) -> float:
     return 2.0 * desc.N * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.KH * desc.KW
+
+
+def host_call(name, *args):
+    """Call a host-side entry point (no stream appended); raise on a non-zero status.
+    BG_E_IO (-3) raises IndexError when the message says 'file corruption' (the reference's
+    test contract, tests/reader_test.py:192-209), RuntimeError otherwise."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.bg_last_error().decode()
+        if "file corruption" in msg:
+            raise IndexError(f"{name}: {msg}")
+        raise RuntimeError(f"{name} failed ({rc}): {msg}")
 
 
 def call(name, *args):

@@ -222,6 +222,44 @@ int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf1
                  float bias_corr2, float grad_scale, void* stream);
 int bg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Data path: .npy header parser and the pinned-host -> HBM asynchronous staging
+ * ring that replaces the reference's synchronous numpy_reader
+ * (src/numpy_reader/cpp/numpy_reader.cpp:60-170 ParseFile, :403-431 readChunk,
+ * :434-497 getSample/getBatch; pybind surface :501-536).
+ * ------------------------------------------------------------------------- */
+#define BG_E_IO (-3) /* file could not be opened / parsed / read completely */
+
+typedef struct bg_npy_info {
+    int32_t dtype_code;    /* 0 '<f4', 1 '<f8', 2 '<i4', 3 '<i8' (the reference's type map, numpy_reader.h:72-77) */
+    int32_t typesize;
+    int32_t fortran_order;
+    int32_t ndim;          /* 0 for a scalar array */
+    int64_t shape[8];
+    int64_t data_offset;   /* first payload byte (format 1.0, 2.0 and 3.0 headers) */
+    int64_t file_size;
+} bg_npy_info;
+/* HOST call.  Errors carry the reference's message fragments ("failed to open file", "not a numpy
+ * file", "ill formatted or corrupt", "unsupported datatype", "big endian"). */
+int bg_npy_parse(const char* path, bg_npy_info* out);
+
+typedef struct bg_ring bg_ring;
+/* device >= 0: n_slots pinned host buffers + n_slots device buffers of slot_bytes, one copy stream,
+ * n_threads reader threads.  device = -1: host-only ring (plain page-aligned memory). */
+int bg_ring_create(int32_t device, int32_t n_slots, int64_t slot_bytes, int32_t n_threads, bg_ring** out);
+int bg_ring_destroy(bg_ring* r);
+/* Start reading nbytes at file offset `offset` of `path` into a free slot, split into n_chunks
+ * parallel preads; returns immediately with a ticket.  BG_E_ARG if every slot is in flight. */
+int bg_ring_submit(bg_ring* r, const char* path, int64_t offset, int64_t nbytes, int32_t n_chunks, int64_t* ticket);
+/* Wait for the read (host) and make consumer_stream wait for the H2D copy (device, no host block);
+ * *ptr = device (or host) address of the payload, valid until bg_ring_release.  A short file gives
+ * BG_E_IO with "file corruption" in the message. */
+int bg_ring_acquire(bg_ring* r, int64_t ticket, void* consumer_stream, void** ptr);
+/* acquire + asynchronous copy of the payload to dst (device memory on consumer_stream / host memory). */
+int bg_ring_copy_out(bg_ring* r, int64_t ticket, void* dst, int64_t nbytes, void* consumer_stream);
+/* Give the slot back; the next copy into it is ordered after consumer_stream's work so far. */
+int bg_ring_release(bg_ring* r, int64_t ticket, void* consumer_stream);
+
 #ifdef __cplusplus
 }
 #endif
