@@ -36,13 +36,28 @@ class GANTrainer:
         self.freq_g, self.freq_d = update_frequency_generator, update_frequency_discriminator
         self.step_count = 0
         self._d_pending = False
+        # the generator forward of the D-step has no data dependence on D(real): run them on two HIP
+        # streams so the tails of one network's kernels overlap the other's (BGAMD_NO_SIDE_STREAM=1 disables)
+        import os
+        self._side = None if os.environ.get("BGAMD_NO_SIDE_STREAM") else "auto"
         self._d_params = [p for p in _unwrap(discriminator).parameters()]
 
     # -- train_gan.py:250-271 -------------------------------------------------------------
     def d_step(self, inputs, outputs_real, labels=None, eta=None):
-        with torch.no_grad():                       # no graph through G: D's update cannot use it
-            outputs_fake = self.generator(inputs)
-        logits_real, _ = self.discriminator(outputs_real)
+        if self._side == "auto":
+            self._side = torch.cuda.Stream(device=inputs.device) if inputs.is_cuda else None
+        if self._side is not None:
+            main = torch.cuda.current_stream(inputs.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side), torch.no_grad():
+                outputs_fake = self.generator(inputs)
+            logits_real, _ = self.discriminator(outputs_real)    # concurrently on the main stream
+            main.wait_stream(self._side)
+            outputs_fake.record_stream(main)
+        else:
+            with torch.no_grad():                   # no graph through G: D's update cannot use it
+                outputs_fake = self.generator(inputs)
+            logits_real, _ = self.discriminator(outputs_real)
         logits_fake, _ = self.discriminator(outputs_fake)
         if labels is not None:
             d_loss = self.criterion_gan.d_loss(logits_real, logits_fake, labels)
