@@ -185,8 +185,10 @@ def main():
     # ---- roofline: one extra (un-timed) step with HIP events around every C-ABI launch
     if rank == 0 and not args.no_kernel_profile:
         L.PROFILE = []
+        side, trainer._side = trainer._side, None   # one stream for this step: events then bracket ONE kernel each
         trainer.step(*batches[0])
         torch.cuda.synchronize()
+        trainer._side = side
         recs, L.PROFILE = L.PROFILE, None
         fam = {}
         for name, flops, e0, e1 in recs:
@@ -196,12 +198,24 @@ def main():
             f[2] += flops
         mfma = {k: v for k, v in fam.items() if k.startswith("bg_conv2d")}
         dom = max(mfma, key=lambda k: mfma[k][1])
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same
+        # command (profiles/*_pmc_hbm_traffic.json, FETCH_SIZE corrected per MI355X_MICROARCH.md);
+        # PMC collection needs the profiler, so it is not re-measured inside this process.
+        traffic = None
+        try:
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]
+            for fam_name, rec in json.load(open(pj))["kernels"].items():
+                if dom.replace("_stats", "") in fam_name.split("+"):
+                    traffic = rec["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         cnt, secs, flops = mfma[dom]
         achieved = flops / secs * 1e-12
         walg = W_ALG_TFLOP.get((h, w, c))
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
-            "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": traffic,
             "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt, "alg_gflop_per_launch": flops / cnt * 1e-9,
             "step_conv_stack_tflops": None if walg is None else value / world * walg,
             "step_conv_stack_frac": None if walg is None else value / world * walg / PEAK_BF16_TFLOPS,
