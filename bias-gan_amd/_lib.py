@@ -59,6 +59,10 @@ _SIGS = {
                          c_vp],
     "bg_norm_eval_affine": [c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp],
     "bg_norm_act_fwd": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_norm_act_fwd_stats": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                              c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_norm_act_bwd_apply_stats": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                    c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
     "bg_norm_act_bwd_reduce": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
                                c_vp, c_vp, c_vp],
     "bg_norm_bwd_finalize": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...runtime import BGModule, pad_to, vec_of
+from ...runtime import BGModule, StatsPool, pad_to, vec_of
 
 
 class Identity(nn.Module):
@@ -116,7 +116,7 @@ def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
     stats = None
     if isinstance(m, nn.BatchNorm2d) and m.training and dense.bias is None and _FUSED_STATS:
         kp = owner.arena().by_param[id(dense.weight)].phys_shape[0]
-        stats = torch.zeros((2, kp), dtype=torch.float64, device=x.device)
+        stats = StatsPool.get(x.device).take(2, kp)
     y = conv(x, stats) if stats is not None else conv(x)
     return apply_norm(owner, m, y, res=res, act=act, stats=stats)
 

@@ -241,6 +241,12 @@ struct EwParams {
     const void* res; int ldres;
     void* y; int ldy;
     int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
+    // fused finalize (training-mode statistics -> affine) when sum != NULL
+    const double* sum; const double* sumsq;
+    const float* gamma; const float* beta;
+    float eps, momentum;
+    float* rmean; float* rvar;      // running statistics (batch norm, groups == 1) or NULL
+    float* mean_out; float* rstd_out;
 };
 
 template <typename T>
@@ -257,10 +263,40 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
     float sc[VEC], sh[VEC];
+    if (P.sum) {
+        // every thread derives the affine of its own channels from the fp64 sums (a few flops);
+        // the first row-block of each group also publishes mean / rstd for the backward pass
+        // and applies the BatchNorm running-statistics update -- no separate finalize launch
+        const bool publish = blockIdx.y == 0 && ly == 0;
+        const double n = (double)P.rows_per_group;
+        const double inv_n = 1.0 / n;  // one fp64 division per thread; the rest is fp64 mul/add + one fp32 rsqrt
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        sc[e] = P.scale ? P.scale[(long long)g * P.C + c + e] : 1.f;
-        sh[e] = P.scale ? P.shift[(long long)g * P.C + c + e] : 0.f;
+        for (int e = 0; e < VEC; ++e) {
+            const long long i = (long long)g * P.C + c + e;
+            const double m = P.sum[i] * inv_n;
+            double var = P.sumsq[i] * inv_n - m * m;  // the cancellation-prone step stays in fp64
+            if (var < 0.0 || P.rows_per_group == 1) var = 0.0;
+            const float r = rsqrtf((float)var + P.eps);
+            const float gm = P.gamma ? P.gamma[c + e] : 1.f;
+            const float bt = P.beta ? P.beta[c + e] : 0.f;
+            sc[e] = gm * r;
+            sh[e] = bt - (float)m * gm * r;
+            if (publish) {
+                P.mean_out[i] = (float)m;
+                P.rstd_out[i] = r;
+                if (P.rmean) {
+                    const double unb = P.rows_per_group > 1 ? var * n / (n - 1.0) : var;
+                    P.rmean[c + e] = (1.f - P.momentum) * P.rmean[c + e] + P.momentum * (float)m;
+                    P.rvar[c + e] = (1.f - P.momentum) * P.rvar[c + e] + P.momentum * (float)unb;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sc[e] = P.scale ? P.scale[(long long)g * P.C + c + e] : 1.f;
+            sh[e] = P.scale ? P.shift[(long long)g * P.C + c + e] : 0.f;
+        }
     }
     const T* x = reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c;
     const T* res = P.res ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
@@ -292,6 +328,11 @@ struct EwBwdParams {
     void* dx; int lddx;
     void* dres; int lddres;
     int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
+    // fused finalize when s1 != NULL: coefficients from the fp64 sums, dgamma/dbeta by the first row-block
+    const double* s1; const double* s2;
+    const float* gamma; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta;
+    int train; int groups;
 };
 
 template <typename T>
@@ -307,17 +348,45 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
-    const bool useB = P.A && P.B;
+    const bool useB = P.s1 ? (P.train != 0) : (P.A && P.B);
     float ca[VEC], cb[VEC], cc[VEC];
+    if (P.s1) {
+        const float inv_n = 1.f / (float)P.rows_per_group;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const long long so = (long long)g * P.C + c + e;
-        ca[e] = P.A ? P.A[so] : 1.f;
-        cb[e] = useB ? P.B[so] : 0.f;
-        cc[e] = useB ? P.Cc[so] : 0.f;
+        for (int e = 0; e < VEC; ++e) {
+            const long long i = (long long)g * P.C + c + e;
+            const float gm = P.gamma ? P.gamma[c + e] : 1.f;
+            const float r = P.rstd[i], m = P.mean[i];
+            const float a1 = (float)P.s1[i] * inv_n, a2 = (float)P.s2[i] * inv_n;  // means of g and g*xhat
+            ca[e] = gm * r;
+            cb[e] = P.train ? -gm * r * r * a2 : 0.f;
+            cc[e] = P.train ? gm * r * (r * a2 * m - a1) : 0.f;
+        }
+        if (P.dgamma && blockIdx.y == 0 && ly == 0 && g == 0) {
+            // parameter gradients: sum over groups (one thread per channel, once)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int gg = 0; gg < P.groups; ++gg) {
+                    t1 += P.s1[(long long)gg * P.C + c + e];
+                    t2 += P.s2[(long long)gg * P.C + c + e];
+                }
+                P.dgamma[c + e] += (float)t2;
+                P.dbeta[c + e] += (float)t1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const long long so = (long long)g * P.C + c + e;
+            ca[e] = P.A ? P.A[so] : 1.f;
+            cb[e] = useB ? P.B[so] : 0.f;
+            cc[e] = useB ? P.Cc[so] : 0.f;
+        }
     }
     const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;
     const T* y = P.act ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
+    const bool scaleA = P.s1 || P.A;
     const T* x = useB ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
     T* dx = P.dx ? reinterpret_cast<T*>(P.dx) + row0 * P.lddx + c : nullptr;
     T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + row0 * P.lddres + c : nullptr;
@@ -345,7 +414,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
         if (dx) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float d = gg[e] * ca[e];
+                float d = scaleA ? gg[e] * ca[e] : gg[e];
                 if (useB) d += fmaf(cb[e], vx.get(e), cc[e]);
                 vo.set(e, d);
             }
@@ -469,7 +538,8 @@ extern "C" int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const 
     }
     const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd: too many groups");
-    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx};
+    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
+               nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_fwd_kernel");
@@ -504,9 +574,73 @@ extern "C" int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy
     const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply: too many groups");
     EwBwdParams P{dy, lddy, y, ldy, x, ldx, A, B, Cc, dx, lddx, dres, lddres, C, rows / groups, t.rows_per_block, act,
-                  t.tx, t.log_tx};
+                  t.tx, t.log_tx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, groups};
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, const double* sum, const double* sumsq,
+                                     const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, float* mean, float* rstd, const void* res,
+                                     int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
+                                     int32_t act, void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_fwd_stats");
+    if (rc) return rc;
+    CHECK_LD(ldx, "bg_norm_act_fwd_stats");
+    CHECK_LD(ldy, "bg_norm_act_fwd_stats");
+    BG_CHECK_ARG(x && y && sum && sumsq && mean && rstd && aligned16(x) && aligned16(y),
+                 "bg_norm_act_fwd_stats: null/unaligned pointer");
+    BG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && !(running_mean && groups != 1),
+                 "bg_norm_act_fwd_stats: running statistics need batch statistics (groups == 1), both or none");
+    if (res) {
+        BG_CHECK_ARG(aligned16(res), "bg_norm_act_fwd_stats: unaligned res");
+        CHECK_LD(ldres, "bg_norm_act_fwd_stats");
+    }
+    // fewer, longer-running threads than the plain apply kernel: each thread first derives its
+    // channels' affine from the sums, which must be amortised over the rows it then walks
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 16, 2048);
+    BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd_stats: too many groups");
+    EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
+               sum, sumsq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd};
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
+                                                   (hipStream_t)stream, P));
+    BG_CHECK_LAUNCH("norm_act_fwd_kernel(stats)");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
+                                           const void* x, int32_t ldx, const double* s1, const double* s2,
+                                           const float* gamma, const float* mean, const float* rstd, int32_t train,
+                                           float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
+                                           int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
+                                           void* stream) {
+    int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_apply_stats");
+    if (rc) return rc;
+    CHECK_LD(lddy, "bg_norm_act_bwd_apply_stats");
+    CHECK_LD(ldx, "bg_norm_act_bwd_apply_stats");
+    BG_CHECK_ARG(dy && x && s1 && s2 && mean && rstd && aligned16(dy) && aligned16(x) && (dx || dres || dgamma),
+                 "bg_norm_act_bwd_apply_stats: null/unaligned pointer");
+    BG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "bg_norm_act_bwd_apply_stats: dgamma/dbeta in pairs");
+    if (act) {
+        BG_CHECK_ARG(y && aligned16(y), "bg_norm_act_bwd_apply_stats: act needs y");
+        CHECK_LD(ldy, "bg_norm_act_bwd_apply_stats");
+    }
+    if (dx) {
+        BG_CHECK_ARG(aligned16(dx), "bg_norm_act_bwd_apply_stats: unaligned dx");
+        CHECK_LD(lddx, "bg_norm_act_bwd_apply_stats");
+    }
+    if (dres) {
+        BG_CHECK_ARG(aligned16(dres), "bg_norm_act_bwd_apply_stats: unaligned dres");
+        CHECK_LD(lddres, "bg_norm_act_bwd_apply_stats");
+    }
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 16, 2048);
+    BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply_stats: too many groups");
+    EwBwdParams P{dy, lddy, y, ldy, x, ldx, nullptr, nullptr, nullptr, dx, lddx, dres, lddres, C, rows / groups,
+                  t.rows_per_block, act, t.tx, t.log_tx, s1, s2, gamma, mean, rstd, dgamma, dbeta, train, groups};
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
+                                                   (hipStream_t)stream, P));
+    BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel(stats)");
     return BG_OK;
 }

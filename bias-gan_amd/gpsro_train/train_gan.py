@@ -14,6 +14,7 @@ import torch
 
 from ..architecture.gpsro import deeplab_gan as dxg
 from ..comm.distributed import DistributedModel
+from ..runtime import StatsPool
 
 
 def _unwrap(m):
@@ -115,6 +116,7 @@ class GANTrainer:
         D's optimiser step is issued inside g_step after the generator forward has
         been enqueued: the generator forward does not read D, so under data
         parallelism D's gradient all-reduce runs on the RCCL stream beneath it."""
+        StatsPool.reset_all()   # one fill clears every statistic accumulator of the previous step
         s = self.step_count
         train_generator = (s < self.warmup) or (s % self.freq_g == 0)            # train_gan.py:247
         train_discriminator = (s >= self.warmup) and (s % self.freq_d == 0)      # train_gan.py:248

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib as L
-from .runtime import Arena, ParamSlot
+from .runtime import Arena, ParamSlot, StatsPool
 
 
 # --------------------------------------------------------------------------- helpers
@@ -74,7 +74,8 @@ def _f32(*shape, device):
 
 
 def _f64(*shape, device):
-    return torch.zeros(shape, dtype=torch.float64, device=device)
+    """Zeroed fp64 statistic accumulators (slices of the per-device StatsPool)."""
+    return StatsPool.get(device).take(*shape)
 
 
 def _e32(*shape, device):
@@ -239,28 +240,30 @@ class NormActFn(torch.autograd.Function):
         use_batch_stats = (kind == "batch" and training) or kind == "instance"
         groups = n if kind == "instance" else 1
         mean = rstd = scale = shift = None
-        if kind != "identity":
-            mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
-            gptr = None if gslot is None else arena.master_ptr(gslot)
-            bptr = None if bslot is None else arena.master_ptr(bslot)
-            if use_batch_stats:
-                if pre_stats is not None and groups == 1:
-                    s = pre_stats.view(2, 1, c)
-                else:
-                    s = _f64(2, groups, c, device=dev)
-                    L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
-                upd = kind == "batch" and rmean is not None
-                L.call("bg_norm_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, bptr, eps,
-                       momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                       rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
-            else:  # BatchNorm in eval mode
+        y = new_act(n, h, w, c, x.dtype, dev)
+        gptr = None if gslot is None else arena.master_ptr(gslot)
+        bptr = None if bslot is None else arena.master_ptr(bslot)
+        if kind != "identity" and use_batch_stats:
+            if pre_stats is not None and groups == 1:
+                s = pre_stats.view(2, 1, c)
+            else:
+                s = _f64(2, groups, c, device=dev)
+                L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
+            mean, rstd = _e32(2, groups, c, device=dev).unbind(0)
+            upd = kind == "batch" and rmean is not None
+            # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
+            L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
+                   momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
+                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), c, rows, c, groups, int(act))
+        else:
+            if kind != "identity":  # BatchNorm in eval mode: affine from the running statistics
+                mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
                 L.call("bg_norm_eval_affine", c, gptr, bptr, rmean.data_ptr(), rvar.data_ptr(), eps, scale.data_ptr(),
                        shift.data_ptr())
                 mean.copy_(rmean.view(1, -1))
                 rstd.copy_(torch.rsqrt(rvar + eps).view(1, -1))
-        y = new_act(n, h, w, c, x.dtype, dev)
-        L.call("bg_norm_act_fwd", dt, x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(res),
-               0 if res is None else ld_of(res), y.data_ptr(), c, rows, c, groups, int(act))
+            L.call("bg_norm_act_fwd", dt, x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(res),
+                   0 if res is None else ld_of(res), y.data_ptr(), c, rows, c, groups, int(act))
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.meta = (arena, gslot, bslot, kind, use_batch_stats, int(act), groups, res is not None)
         return y
@@ -290,19 +293,15 @@ class NormActFn(torch.autograd.Function):
             s = _f64(2, groups, c, device=dev)
             L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
                    mean.data_ptr(), rstd.data_ptr(), rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
-            coef = _e32(3, groups, c, device=dev)
             dg = db = None
             if want_affine_grads:
                 arena.ensure_grad(gslot)
                 arena.ensure_grad(bslot)
                 dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
-            L.call("bg_norm_bwd_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
-                   None if gslot is None else arena.master_ptr(gslot), mean.data_ptr(), rstd.data_ptr(),
-                   1 if batch_stats else 0, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), dg, db)
-            if need_dx or need_res:
-                L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
-                       coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), L.ptr(dx), c, L.ptr(dres), c, rows, c,
-                       groups, act)
+            # finalize (coefficients, dgamma/dbeta) is folded into the apply kernel
+            L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
+                   s[0].data_ptr(), s[1].data_ptr(), None if gslot is None else arena.master_ptr(gslot), mean.data_ptr(),
+                   rstd.data_ptr(), 1 if batch_stats else 0, dg, db, L.ptr(dx), c, L.ptr(dres), c, rows, c, groups, act)
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None, None, 0,
                    dres.data_ptr(), c, rows, c, groups, act)

@@ -50,6 +50,45 @@ class ParamSlot:
         self.krsc = None  # (K, RS, C, Cp, Kp) for dense convs
 
 
+class StatsPool:
+    """Zero-initialised fp64 scratch for per-channel statistic sums, handed out as slices of one
+    buffer that is cleared with ONE fill per training step (GANTrainer.step calls reset()),
+    instead of one torch.zeros launch per normalisation layer and direction (~600 per step)."""
+    _pools = {}
+
+    def __init__(self, device, n=1 << 21):
+        self.buf = torch.zeros(n, dtype=torch.float64, device=device)
+        self.used = 0
+
+    @classmethod
+    def get(cls, device) -> "StatsPool":
+        key = (device.type, device.index)
+        if key not in cls._pools:
+            cls._pools[key] = StatsPool(device)
+        return cls._pools[key]
+
+    def take(self, *shape) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        n_al = (n + 31) // 32 * 32
+        if self.used + n_al > self.buf.numel():   # exhausted (nobody resets): plain allocation
+            return torch.zeros(shape, dtype=torch.float64, device=self.buf.device)
+        out = self.buf[self.used:self.used + n].view(shape)
+        self.used += n_al
+        return out
+
+    def reset(self):
+        if self.used:
+            self.buf[:self.used].zero_()
+            self.used = 0
+
+    @classmethod
+    def reset_all(cls):
+        for p in cls._pools.values():
+            p.reset()
+
+
 _ARENA_OF = {}  # id(param) -> weakref to its arena
 
 

@@ -137,6 +137,13 @@ int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const 
 int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
                     const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
                     int32_t act, void* stream);
+/* bg_norm_finalize + bg_norm_act_fwd in ONE launch (training-mode statistics): every thread derives
+ * the affine of its channels from the fp64 sums; the first row-block of each group also writes
+ * mean/rstd (fp32 [groups,C]) and applies the running-statistics update. */
+int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, const double* sum, const double* sumsq,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, float* mean, float* rstd, const void* res, int32_t ldres, void* y,
+                          int32_t ldy, int64_t rows, int32_t C, int32_t groups, int32_t act, void* stream);
 /* Backward pass 1: g = dy * act'(y);  s1[g,c] += sum g, s2[g,c] += sum g*xhat
  * (fp64, caller zeroes) with xhat = (x-mean)*rstd. */
 int bg_norm_act_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
@@ -154,6 +161,14 @@ int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const voi
                           int32_t ldx, const float* A, const float* B, const float* Cc, void* dx, int32_t lddx,
                           void* dres, int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
                           void* stream);
+
+/* bg_norm_bwd_finalize + bg_norm_act_bwd_apply in ONE launch: coefficients from s1/s2 per thread,
+ * dgamma += sum_g s2 and dbeta += sum_g s1 by the first row-block (both may be NULL). */
+int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
+                                int32_t ldx, const double* s1, const double* s2, const float* gamma, const float* mean,
+                                const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx, int32_t lddx,
+                                void* dres, int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------
  * Resampling / pooling / layout (deeplab.py:375,379,663 bilinear

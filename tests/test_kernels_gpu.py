@@ -468,3 +468,59 @@ def test_conv_fwd_fused_statistics(dtype):
     assert_close(from_nhwc(yb, cout), F.conv2d(x, wt, None, 1, 1, 1), tol(dtype), "fwd")
     assert_close(st[0].cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
     assert_close(st[1].cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["batch", "instance"])
+def test_norm_act_fused_finalize_matches_split(dtype, mode):
+    """bg_norm_act_fwd_stats / bg_norm_act_bwd_apply_stats (finalize folded into the apply kernels)
+    against the three-launch sequence they replace."""
+    n, h, w, c = 3, 11, 9, 40
+    x = (rnd((n, c, h, w), 31, dtype, 2.0) + 0.5).to(dtype).float()
+    res, go = rnd((n, c, h, w), 32, dtype), rnd((n, c, h, w), 33, dtype)
+    rows, groups, dtc = n * h * w, (n if mode == "instance" else 1), L.dt(dtype)
+    (xb, xv), (rb, rv), (gb, gv) = to_nhwc(x, dtype), to_nhwc(res, dtype), to_nhwc(go, dtype)
+    aff = mode == "batch"
+    gamma = (torch.rand(c) + 0.5).to(DEV) if aff else None
+    beta = (torch.randn(c) * 0.2).to(DEV) if aff else None
+    f32 = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    f64 = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.float64)  # noqa: E731
+    s, ss = f64(groups, c), f64(groups, c)
+    L.call("bg_norm_stats", dtc, xv.data_ptr(), rows, c, c, groups, s.data_ptr(), ss.data_ptr())
+    out = {}
+    for fused in (False, True):
+        rm, rvv = (torch.full((c,), 0.1, device=DEV), torch.full((c,), 0.9, device=DEV)) if aff else (None, None)
+        mean, rstd, scale, shift = f32(groups, c), f32(groups, c), f32(groups, c), f32(groups, c)
+        y = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+        if fused:
+            L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), c, s.data_ptr(), ss.data_ptr(), L.ptr(gamma), L.ptr(beta),
+                   1e-5, 0.1, L.ptr(rm), L.ptr(rvv), mean.data_ptr(), rstd.data_ptr(), rv.data_ptr(), c, y.data_ptr(), c,
+                   rows, c, groups, 1)
+        else:
+            L.call("bg_norm_finalize", s.data_ptr(), ss.data_ptr(), rows // groups, groups, c, L.ptr(gamma), L.ptr(beta),
+                   1e-5, 0.1, L.ptr(rm), L.ptr(rvv), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            L.call("bg_norm_act_fwd", dtc, xv.data_ptr(), c, scale.data_ptr(), shift.data_ptr(), rv.data_ptr(), c,
+                   y.data_ptr(), c, rows, c, groups, 1)
+        s1, s2 = f64(groups, c), f64(groups, c)
+        L.call("bg_norm_act_bwd_reduce", dtc, gv.data_ptr(), c, y.data_ptr(), c, xv.data_ptr(), c, mean.data_ptr(),
+               rstd.data_ptr(), rows, c, groups, 1, s1.data_ptr(), s2.data_ptr())
+        dx = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+        dres = torch.zeros_like(dx)
+        dg, db = (f32(c), f32(c)) if aff else (None, None)
+        if fused:
+            L.call("bg_norm_act_bwd_apply_stats", dtc, gv.data_ptr(), c, y.data_ptr(), c, xv.data_ptr(), c, s1.data_ptr(),
+                   s2.data_ptr(), L.ptr(gamma), mean.data_ptr(), rstd.data_ptr(), 1, L.ptr(dg), L.ptr(db), dx.data_ptr(), c,
+                   dres.data_ptr(), c, rows, c, groups, 1)
+        else:
+            A, B, Cc = f32(groups, c), f32(groups, c), f32(groups, c)
+            L.call("bg_norm_bwd_finalize", s1.data_ptr(), s2.data_ptr(), rows // groups, groups, c, L.ptr(gamma),
+                   mean.data_ptr(), rstd.data_ptr(), 1, A.data_ptr(), B.data_ptr(), Cc.data_ptr(), L.ptr(dg), L.ptr(db))
+            L.call("bg_norm_act_bwd_apply", dtc, gv.data_ptr(), c, y.data_ptr(), c, xv.data_ptr(), c, A.data_ptr(),
+                   B.data_ptr(), Cc.data_ptr(), dx.data_ptr(), c, dres.data_ptr(), c, rows, c, groups, 1)
+        out[fused] = dict(y=y.float().cpu(), dx=dx.float().cpu(), dres=dres.float().cpu(), mean=mean.cpu(), rstd=rstd.cpu(),
+                          rm=None if rm is None else rm.cpu(), rv=None if rvv is None else rvv.cpu(),
+                          dg=None if dg is None else dg.cpu(), db=None if db is None else db.cpu())
+    a, b = out[False], out[True]
+    for k in a:
+        if a[k] is not None:
+            assert_close(b[k], a[k], 2e-5 if dtype == torch.float32 else 1e-2, k)
