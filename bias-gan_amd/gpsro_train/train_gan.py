@@ -128,3 +128,56 @@ class GANTrainer:
         self._finish_d()
         self.step_count += 1
         return d_loss, g_loss
+
+
+    # -- train_gan.py:330-398 -----------------------------------------------------------
+    @torch.no_grad()
+    def validate(self, loader, comm=None):
+        """Eval-mode pass over a validation loader: returns (d_loss, g_loss) averaged over
+        all samples of all ranks (three summed all-reduces, like train_gan.py:377-386)."""
+        G, D = self.generator, self.discriminator
+        G.eval(), D.eval()
+        dev = next(_unwrap(G).parameters()).device
+        count = torch.zeros((), device=dev)
+        d_sum = torch.zeros((), device=dev)
+        g_sum = torch.zeros((), device=dev)
+        try:
+            for batch in loader:
+                inputs, outputs_real = batch[0], batch[1]
+                masks = batch[2] if self.enable_masks else None
+                outputs_fake = G(inputs)
+                logits_real, _ = D(outputs_real)
+                logits_fake, _ = D(outputs_fake)
+                d_loss = self.criterion_gan.d_loss(logits_real, logits_fake)
+                gan_loss = self.criterion_gan.g_loss(logits_fake)
+                if self.enable_masks:
+                    reg = self.criterion_regression(outputs_fake, outputs_real, masks)
+                else:
+                    reg = self.criterion_regression(outputs_fake, outputs_real)
+                n = float(inputs.shape[0])
+                count += n
+                d_sum += n * d_loss
+                g_sum += n * (self.w_gan * gan_loss + self.w_reg * reg)
+        finally:
+            G.train(), D.train()
+        if comm is not None and comm.size() > 1:
+            import torch.distributed as dist
+            for t in (count, d_sum, g_sum):
+                dist.all_reduce(t)
+        c = max(float(count), 1.0)
+        return float(d_sum) / c, float(g_sum) / c
+
+    # -- train_gan.py:401-431 / comm/distributed.py:130-157 -------------------------------
+    def save_checkpoint(self, path, epoch=0):
+        """{step, epoch, generator, discriminator, g_opt, d_opt, amp}: the reference's dictionary, with
+        the reference's state_dict key names (DistributedModel adds the 'module.' prefix like DDP)."""
+        torch.save({"step": self.step_count, "epoch": epoch,
+                    "generator": {k: v.detach().clone().contiguous() for k, v in self.generator.state_dict().items()},
+                    "discriminator": {k: v.detach().clone().contiguous()
+                                      for k, v in self.discriminator.state_dict().items()},
+                    "g_opt": self.g_opt.state_dict(), "d_opt": self.d_opt.state_dict(), "amp": None}, path)
+
+    def load_checkpoint(self, path, comm, device):
+        self.step_count, epoch = comm.init_gan_training_state(_unwrap(self.generator), _unwrap(self.discriminator),
+                                                              self.g_opt, self.d_opt, path, device)
+        return self.step_count, epoch

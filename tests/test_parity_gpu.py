@@ -343,3 +343,54 @@ def test_full_size_properties_bf16():
     g_all = grads(x)
     g_sum = grads(x[:4]) + grads(x[4:])
     assert rel_err(g_sum.cpu(), g_all.cpu()) <= 2e-2  # float atomics order + bf16 re-rounding of activations
+
+
+def test_validation_and_checkpoint_roundtrip(tmp_path, golden_dir):
+    """train_gan.py:330-431: eval-mode validation leaves the models untouched and in train
+    mode; a checkpoint written after a step restores parameters, buffers and Adam state so
+    that the NEXT step is bit-identical; a reference-format dictionary (plain state_dict
+    keys, 'module.' prefixes) loads through comm.init_gan_training_state."""
+    from bias_gan_amd.comm.distributed import comm as distcomm
+    z, m = gz(golden_dir, "trajectory_mmm.npz")
+    c, h, w, n = m["c"], m["h"], m["w"], m["n"]
+
+    def make():
+        G, _ = build_generator(c, m["seed"], F32)
+        D, _ = build_discriminator(c, h, w, m["seed"] + 1, F32)
+        G.train(), D.train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        return GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5),
+                          ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5), crit, losses.L1Loss())
+
+    x0, y0 = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 1000))
+    x1, y1 = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 1001))
+    tr = make()
+    labels = tr.criterion_gan.draw_labels()
+    tr.step(x0, y0, labels=labels)
+    before = {k: v.clone() for k, v in tr.generator.state_dict().items()}
+    torch.manual_seed(5)
+    vd, vg = tr.validate([(x0, y0), (x1, y1)], distcomm(mode="dummy"))
+    assert np.isfinite(vd) and np.isfinite(vg) and tr.generator.training and tr.discriminator.training
+    after = tr.generator.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)   # eval mode: no running-stat updates
+    ck = str(tmp_path / "ck_step_1.cpt")
+    tr.save_checkpoint(ck, epoch=3)
+    d1, g1 = tr.step(x1, y1, labels=labels)
+    tr2 = make()
+    tr2.step(x0, y0, labels=labels)                 # builds arenas / optimiser state, then overwritten
+    assert tr2.load_checkpoint(ck, distcomm(mode="dummy"), DEV) == (1, 3)
+    d2, g2 = tr2.step(x1, y1, labels=labels)
+    assert abs(d1.item() - d2.item()) <= 1e-6 * abs(d1.item()) and abs(g1.item() - g2.item()) <= 1e-5 * abs(g1.item())
+    # reference-style dictionary with DDP prefixes
+    ref_like = torch.load(ck)
+    ref_like["generator"] = {"module." + k: v for k, v in ref_like["generator"].items()}
+    ref_like["discriminator"] = {"module." + k: v for k, v in ref_like["discriminator"].items()}
+    ck2 = str(tmp_path / "ck_ddp.cpt")
+    torch.save(ref_like, ck2)
+    tr3 = make()
+    tr3.step(x0, y0, labels=labels)
+    assert tr3.load_checkpoint(ck2, distcomm(mode="dummy"), DEV) == (1, 3)
+    sd1, sd3 = tr.generator.state_dict(), tr3.generator.state_dict()
+    k0 = "model.xception_features.block7.rep.1.pointwise.weight"
+    assert not torch.equal(sd1[k0], sd3[k0])        # tr took one more step than the checkpoint
+    assert torch.equal(torch.load(ck)["generator"][k0].to(DEV), sd3[k0])
