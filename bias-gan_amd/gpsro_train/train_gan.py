@@ -178,6 +178,165 @@ class GANTrainer:
                     "g_opt": self.g_opt.state_dict(), "d_opt": self.d_opt.state_dict(), "amp": None}, path)
 
     def load_checkpoint(self, path, comm, device):
+        # the optimiser moments are flat buffers over the parameter arenas: build those first
+        _unwrap(self.generator).arena(), _unwrap(self.discriminator).arena()
         self.step_count, epoch = comm.init_gan_training_state(_unwrap(self.generator), _unwrap(self.discriminator),
                                                               self.g_opt, self.d_opt, path, device)
         return self.step_count, epoch
+
+
+# ----------------------------------------------------------------------------------------
+# Command line with the reference's flag names (train_gan.py:440-486).  wandb logging and the
+# matplotlib visualiser are harness and left out; everything on the step path is here.
+def main(pargs):
+    import datetime as dt
+    import os
+
+    import torch.nn as nn
+    from torch.utils.data import DataLoader
+
+    from ..architecture.gpsro import deeplab as dxc
+    from ..comm.distributed import comm as distcomm
+    from ..data import gpsro_dataset as gpsro
+    from ..utils import losses
+    from ..utils import parsing_helpers as ph
+
+    comm = distcomm(mode="dummy" if "RANK" not in os.environ else "torchrun")
+    seed = 333 + 7 * comm.rank()                                   # train_gan.py:56
+    torch.manual_seed(seed)
+    device = torch.device("cuda", comm.local_rank())
+    torch.cuda.set_device(device)
+    normalizer = dxc.Identity if pargs.disable_batchnorm else nn.BatchNorm2d
+    nch = len(pargs.channels)
+
+    if pargs.synthetic_size is not None:
+        h, w = pargs.synthetic_size
+        g = torch.Generator(device=device).manual_seed(seed)
+
+        def batches():
+            while True:
+                x = torch.randn((pargs.local_batch_size, nch, h, w), generator=g, device=device)
+                yield x, x + 0.1 * torch.randn(x.shape, generator=g, device=device), None, None
+        train_loader, validation_loader, field = batches(), None, (h, w)
+    else:
+        root = pargs.data_dir_prefix
+        kw = dict(statsfile=os.path.join(root, "stats.npz"), channels=pargs.channels,
+                  normalization_type="MinMax" if pargs.noise_type == "Uniform" else "MeanVariance", shuffle=True,
+                  masks=pargs.enable_masks, shard_idx=comm.rank(), shard_num=comm.size(),
+                  num_intra_threads=pargs.max_intra_threads, read_device=device, send_device=device)
+        train_set = gpsro.GPSRODataset(os.path.join(root, "train"), **kw)
+        train_loader = DataLoader(train_set, pargs.local_batch_size, drop_last=True)
+        validation_loader = DataLoader(gpsro.GPSRODataset(os.path.join(root, "validation"), **kw), pargs.local_batch_size,
+                                       drop_last=True)
+        field = tuple(train_set.shapes[0][-2:])
+
+    # apex.amp levels (train_gan.py:159-160) map onto the compute type: O0 is fp32 storage and
+    # arithmetic, O1..O3 are bf16 storage with fp32 accumulation and fp32 master weights.
+    cdt = torch.float32 if pargs.amp_opt_level == "O0" else torch.bfloat16
+    generator = dxg.Generator(nch, nch, pargs.upsampler_type, pargs.noise_type, pargs.noise_dimensions, os=16,
+                              pretrained=False, normalizer=normalizer, compute_dtype=cdt).to(device)
+    discriminator = dxg.Discriminator(n_input=nch, os=16, pretrained=False, normalizer=normalizer, input_size=field,
+                                      compute_dtype=cdt).to(device)
+    criterion_gan = losses.GANLoss(pargs.loss_type_gan, pargs.local_batch_size, device)
+    if pargs.loss_type_regression != "l1":
+        raise NotImplementedError("Error, loss {} not implemented.".format(pargs.loss_type_regression))
+    criterion_regression = losses.L1LossWeighted() if pargs.enable_masks else losses.L1Loss()
+    g_opt = ph.get_optimizer(generator.parameters(), pargs.optimizer_generator, pargs.start_lr_generator, pargs.adam_eps,
+                             pargs.weight_decay)
+    d_opt = ph.get_optimizer(discriminator.parameters(), pargs.optimizer_discriminator, pargs.start_lr_discriminator,
+                             pargs.adam_eps, pargs.weight_decay)
+    generator.train(), discriminator.train()
+    g_sched = ph.get_lr_schedule(pargs.start_lr_generator, pargs.lr_schedule_generator, g_opt) \
+        if pargs.lr_schedule_generator else None
+    d_sched = ph.get_lr_schedule(pargs.start_lr_discriminator, pargs.lr_schedule_discriminator, d_opt) \
+        if pargs.lr_schedule_discriminator else None
+    trainer = GANTrainer(comm.DistributedModel(generator), comm.DistributedModel(discriminator), g_opt, d_opt, criterion_gan,
+                         criterion_regression, loss_type_gan=pargs.loss_type_gan, loss_weight_gan=pargs.loss_weight_gan,
+                         loss_weight_regression=pargs.loss_weight_regression, loss_weight_gp=pargs.loss_weight_gp,
+                         enable_masks=pargs.enable_masks, generator_warmup_steps=pargs.generator_warmup_steps,
+                         g_scheduler=g_sched, d_scheduler=d_sched,
+                         update_frequency_generator=pargs.update_frequency_generator,
+                         update_frequency_discriminator=pargs.update_frequency_discriminator)
+    if pargs.checkpoint:
+        trainer.load_checkpoint(pargs.checkpoint, comm, device)
+    comm.printr('{:14.4f} REPORT: starting training'.format(dt.datetime.now().timestamp()), 0)
+    epoch, d_avg, g_avg = 0, 0., 0.
+    while trainer.step_count < pargs.max_steps:
+        for batch in train_loader:
+            inputs, outputs_real = batch[0], batch[1]
+            masks = batch[2] if pargs.enable_masks else None
+            d_loss, g_loss = trainer.step(inputs, outputs_real, masks)
+            if trainer.step_count % pargs.logging_frequency == 0 or trainer.step_count == pargs.max_steps:
+                if d_loss is not None:
+                    d_avg = comm.metric_average(d_loss, "train_loss_discriminator", device=device)
+                if g_loss is not None:
+                    g_avg = comm.metric_average(g_loss, "train_loss_generator", device=device)
+                comm.printr('{:14.4f} REPORT training: step {} d_loss {} g_loss {}'.format(
+                    dt.datetime.now().timestamp(), trainer.step_count, d_avg, g_avg), 0)
+            if validation_loader is not None and trainer.step_count % pargs.validation_frequency == 0:
+                vd, vg = trainer.validate(validation_loader, comm)
+                comm.printr('{:14.4f} REPORT validation: step {} d_loss {} g_loss {}'.format(
+                    dt.datetime.now().timestamp(), trainer.step_count, vd, vg), 0)
+            if pargs.save_frequency > 0 and trainer.step_count % pargs.save_frequency == 0 and comm.rank() == 0:
+                trainer.save_checkpoint(os.path.join(pargs.output_dir, "gan_step_{}.cpt".format(trainer.step_count)), epoch)
+            if trainer.step_count >= pargs.max_steps:
+                break
+        epoch += 1
+    return trainer
+
+
+def build_parser():
+    import argparse as ap
+
+    class StoreDictKeyPair(ap.Action):                            # train_gan.py:41-47
+        def __call__(self, parser, namespace, values, option_string=None):
+            setattr(namespace, self.dest, dict(kv.split("=") for kv in values.split(",")))
+
+    AP = ap.ArgumentParser()
+    AP.add_argument("--data_dir_prefix", type=str, default="/", help="dataset root with train/, validation/, stats.npz")
+    AP.add_argument("--output_dir", type=str, default=".")
+    AP.add_argument("--checkpoint", type=str, default=None)
+    AP.add_argument("--channels", type=int, nargs='+', default=list(range(45)))
+    AP.add_argument("--upsampler_type", type=str, default="Interpolate", choices=["Interpolate", "Deconv", "Deconv1x"])
+    AP.add_argument("--noise_type", type=str, default="Uniform", choices=["Uniform", "Normal"])
+    AP.add_argument("--noise_dimensions", type=int, default=1)
+    AP.add_argument("--local_batch_size", type=int, default=1)
+    AP.add_argument("--max_steps", type=int, default=100)
+    AP.add_argument("--generator_warmup_steps", type=int, default=0)
+    AP.add_argument("--update_frequency_generator", type=int, default=1)
+    AP.add_argument("--update_frequency_discriminator", type=int, default=1)
+    AP.add_argument("--optimizer_generator", type=str, default="Adam", choices=["Adam", "AdamW"])
+    AP.add_argument("--optimizer_discriminator", type=str, default="Adam", choices=["Adam", "AdamW"])
+    AP.add_argument("--start_lr_generator", type=float, default=1e-3)
+    AP.add_argument("--start_lr_discriminator", type=float, default=1e-3)
+    AP.add_argument("--adam_eps", type=float, default=1e-8)
+    AP.add_argument("--weight_decay", type=float, default=1e-4)
+    AP.add_argument("--loss_type_gan", type=str, default="ModifiedMinMax", choices=["ModifiedMinMax", "Wasserstein"])
+    AP.add_argument("--loss_type_regression", type=str, default="l1")
+    AP.add_argument("--loss_weight_gan", type=float, default=1.)
+    AP.add_argument("--loss_weight_regression", type=float, default=1.)
+    AP.add_argument("--loss_weight_gp", type=float, default=10.)
+    AP.add_argument("--lr_schedule_generator", action=StoreDictKeyPair, default={})
+    AP.add_argument("--lr_schedule_discriminator", action=StoreDictKeyPair, default={})
+    AP.add_argument("--logging_frequency", type=int, default=10)
+    AP.add_argument("--validation_frequency", type=int, default=100)
+    AP.add_argument("--save_frequency", type=int, default=0)
+    AP.add_argument("--max_intra_threads", type=int, default=8)
+    AP.add_argument("--enable_masks", action='store_true')
+    AP.add_argument("--disable_batchnorm", action='store_true')
+    AP.add_argument("--amp_opt_level", type=str, default="O1", help="O0: fp32; O1..O3: bf16 storage, fp32 accumulate")
+    # accepted for command-line compatibility; logging/visualisation harness is not part of this build
+    AP.add_argument("--run_tag", type=str, default="run")
+    AP.add_argument("--model_prefix", type=str, default="model")
+    AP.add_argument("--max_inter_threads", type=int, default=1)
+    AP.add_argument("--training_visualization_frequency", type=int, default=50)
+    AP.add_argument("--validation_visualization_frequency", type=int, default=5)
+    AP.add_argument("--disable_gds", action='store_true')
+    AP.add_argument("--resume_logging", action='store_true')
+    AP.add_argument("--synthetic_size", type=int, nargs=2, default=None, metavar=("H", "W"),
+                    help="train on synthetic N(0,1) fields of this size instead of a dataset")
+    return AP
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

@@ -81,7 +81,11 @@ class FusedAdam(optim.Optimizer):
         self._t = sd["t"]
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
-        for i, (a, _, _) in enumerate(self._arenas_or_empty()):
+        arenas = self._arenas_or_empty()
+        if not arenas and any(k.startswith("exp_avg_") for k in sd):
+            raise RuntimeError("FusedAdam.load_state_dict: the parameter arenas do not exist yet; call module.arena() "
+                               "(module on the GPU) before restoring optimiser moments")
+        for i, (a, _, _) in enumerate(arenas):
             if f"exp_avg_{i}" in sd:
                 self._m[id(a)] = sd[f"exp_avg_{i}"].to(a.device).clone()
                 self._v[id(a)] = sd[f"exp_avg_sq_{i}"].to(a.device).clone()
