@@ -191,11 +191,12 @@ def main():
         trainer._side = side
         recs, L.PROFILE = L.PROFILE, None
         fam = {}
-        for name, flops, e0, e1 in recs:
-            f = fam.setdefault(name, [0, 0.0, 0.0])
+        for name, flops, e0, e1, nbytes in recs:
+            f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
             f[0] += 1
             f[1] += e0.elapsed_time(e1) * 1e-3
             f[2] += flops
+            f[3] += nbytes
         mfma = {k: v for k, v in fam.items() if k.startswith("bg_conv2d")}
         dom = max(mfma, key=lambda k: mfma[k][1])
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same
@@ -210,7 +211,7 @@ def main():
                     traffic = rec["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-        cnt, secs, flops = mfma[dom]
+        cnt, secs, flops, _ = mfma[dom]
         achieved = flops / secs * 1e-12
         walg = W_ALG_TFLOP.get((h, w, c))
         out["roofline"] = {
@@ -219,7 +220,9 @@ def main():
             "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt, "alg_gflop_per_launch": flops / cnt * 1e-9,
             "step_conv_stack_tflops": None if walg is None else value / world * walg,
             "step_conv_stack_frac": None if walg is None else value / world * walg / PEAK_BF16_TFLOPS,
-            "families": {k: {"launches": v[0], "total_ms": 1e3 * v[1], "tflops": (v[2] / v[1] * 1e-12 if v[1] > 0 else 0.0)}
+            # per entry point: MFMA-bound ones in TFLOP/s, HBM-bound ones in algorithmic GB/s (peak 8000)
+            "families": {k: {"launches": v[0], "total_ms": 1e3 * v[1], "tflops": (v[2] / v[1] * 1e-12 if v[1] > 0 else 0.0),
+                             "alg_gbps": (v[3] / v[1] * 1e-9 if v[1] > 0 else 0.0)}
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -61,10 +61,10 @@ _SIGS = {
     "bg_norm_act_fwd": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
     "bg_norm_act_fwd_stats": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                               c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
-    "bg_norm_act_bwd_apply_stats": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                    c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
-    "bg_norm_act_bwd_reduce": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32,
-                               c_vp, c_vp, c_vp],
+    "bg_norm_act_bwd_apply_stats": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                    c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_norm_act_bwd_reduce": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
+                               c_i32, c_vp, c_vp, c_vp],
     "bg_norm_bwd_finalize": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                              c_vp],
     "bg_norm_act_bwd_apply": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
@@ -153,6 +153,44 @@ def _conv_flops(desc) -> float:
     return 2.0 * desc.N * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.KH * desc.KW
 
 
+def _es(dtype_code) -> int:
+    return 2 if dtype_code == BF16 else 4
+
+
+def _alg_bytes(name, a) -> float:
+    """Algorithmic HBM bytes of one launch of an HBM-bound entry point: every operand
+    element read or written exactly once."""
+    nn = lambda *idx: sum(1 for i in idx if a[i] is not None)  # noqa: E731
+    if name.startswith("bg_dwconv3x3"):
+        d = a[0]
+        return float(d.N) * (d.H * d.W + d.Ho * d.Wo) * d.C * _es(d.dtype)
+    if name == "bg_norm_stats":
+        return float(a[2]) * a[3] * _es(a[0])
+    if name == "bg_norm_act_fwd":
+        return float(a[9]) * a[10] * _es(a[0]) * (2 + nn(5))
+    if name == "bg_norm_act_fwd_stats":
+        return float(a[17]) * a[18] * _es(a[0]) * (2 + nn(13))
+    if name == "bg_norm_act_bwd_reduce":
+        return float(a[11]) * a[12] * _es(a[0]) * nn(1, 3, 5)
+    if name == "bg_norm_act_bwd_apply":
+        return float(a[14]) * a[15] * _es(a[0]) * nn(1, 3, 5, 10, 12)
+    if name == "bg_norm_act_bwd_apply_stats":
+        return float(a[20]) * a[21] * _es(a[0]) * nn(1, 3, 5, 16, 18)
+    if name == "bg_nchw_to_nhwc":
+        return float(a[3]) * a[5] * (4 * a[4] + _es(a[0]) * a[6])
+    if name == "bg_nhwc_to_nchw":
+        return float(a[4]) * a[6] * a[5] * (4 + _es(a[0]))
+    if name == "bg_adam_step":
+        return float(a[5]) * (7 * 4 + (2 if a[4] is not None else 0))
+    if name == "bg_resize_bilinear_fwd":
+        return float(a[6]) * a[11] * (a[7] * a[8] * _es(a[0]) + a[9] * a[10] * _es(a[1]))
+    if name == "bg_resize_bilinear_bwd":
+        return float(a[6]) * a[11] * (a[7] * a[8] * _es(a[1]) + a[9] * a[10] * _es(a[0]))
+    if name == "bg_axpy_rows":
+        return float(a[5]) * a[6] * _es(a[0]) * 3
+    return 0.0
+
+
 def host_call(name, *args):
     """Call a host-side entry point (no stream appended); raise on a non-zero status.
     BG_E_IO (-3) raises IndexError when the message says 'file corruption' (the reference's
@@ -175,7 +213,7 @@ def call(name, *args):
         rc = getattr(lib, name)(*args, stream())
         e1.record()
         flops = _conv_flops(args[0]) if name.startswith("bg_conv2d") else 0.0
-        PROFILE.append((name, flops, e0, e1))
+        PROFILE.append((name, flops, e0, e1, _alg_bytes(name, args)))
     else:
         rc = getattr(lib, name)(*args, stream())
     if rc != 0:

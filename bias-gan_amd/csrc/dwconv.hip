@@ -14,6 +14,7 @@ struct DwParams {
     int N, H, W, C, Ho, Wo, stride, dil, ldx, ldy;
     int items;  // Wo*(C/VEC) (fwd) or W*(C/VEC) (bwd_data): work items of one image row
     int bx;     // 256-thread blocks per image row; the grid is 1-D: rows * bx blocks
+    int rb, bands;  // dw_s1_kernel: output rows per band, bands per image
 };
 
 // 1-D grid -> (image row, block inside the row).  Blocks with the same id % 8 share an
@@ -130,6 +131,88 @@ __global__ __launch_bounds__(256) void dw_fwd_tw_kernel(DwParams P) {
     }
 }
 
+// Stride 1, dilation 1 (all middle-flow units): one thread owns TW = 4 output columns of one
+// channel vector and walks RB consecutive output rows with the 3-row input window held in
+// registers -- every input element is loaded by 1.5 threads instead of 4.5 (L2 -> L1 traffic was
+// the limiter of the per-row kernel above).  Loads are buffer loads with one descriptor per input
+// row: columns left/right of the image and rows above/below it fall outside the descriptor's range
+// and read as zero, which IS the "same" padding -- no branches around the loads.  The next input
+// row is fetched while the current one is being used.  FLIP = 1 reverses the taps (data gradient).
+template <typename T, int FLIP>
+__global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int TW = 4, NCOL = TW + 2;
+    typedef typename Elem<T>::vec_t vec_t;
+    const unsigned cv = P.C / VEC;
+    int band, xblk;
+    dw_block_to_row(P.bx, band, xblk);
+    const unsigned idx = xblk * 256u + threadIdx.x;
+    if (idx >= (unsigned)P.items) return;
+    const unsigned wq = idx / cv;
+    const int c = (int)(idx - wq * cv) * VEC;
+    const int wo0 = (int)wq * TW;
+    const int n = band / P.bands, b = band - n * P.bands;
+    const int ho0 = b * P.rb;
+    const int ho1 = min(ho0 + P.rb, P.Ho);
+    const unsigned row_bytes = (unsigned)P.W * P.ldx * sizeof(T);
+    const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * row_bytes;
+    int voff[NCOL];  // negative (left of the image) -> huge unsigned -> out of range -> 0
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 - 1 + j) * P.ldx + c) * (int)sizeof(T);
+    Chunk<T> wv[9];
+    {
+        const T* w = reinterpret_cast<const T*>(P.w) + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t].load(w + (FLIP ? 8 - t : t) * P.C);
+    }
+    auto load_row = [&](int ih, Chunk<T>(&dst)[NCOL]) {
+        const bool ok = (unsigned)ih < (unsigned)P.H;  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(xn + (long long)(ok ? ih : 0) * row_bytes), 0, ok ? row_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
+    };
+    Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], nx[NCOL];
+    load_row(ho0 - 1, r0);
+    load_row(ho0, r1);
+    load_row(ho0 + 1, r2);
+    T* y = reinterpret_cast<T*>(P.y) + (((long long)n * P.Ho + ho0) * P.Wo + wo0) * P.ldy + c;
+    for (int ho = ho0; ho < ho1; ++ho) {
+        if (ho + 1 < ho1) load_row(ho + 2, nx);  // prefetch: consumed in the next iteration
+        float acc[TW][VEC];
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    acc[t][e] = fmaf(r0[t + s].get(e), wv[0 + s].get(e), acc[t][e]);
+                    acc[t][e] = fmaf(r1[t + s].get(e), wv[3 + s].get(e), acc[t][e]);
+                    acc[t][e] = fmaf(r2[t + s].get(e), wv[6 + s].get(e), acc[t][e]);
+                }
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            if (wo0 + t < P.Wo) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.set(e, acc[t][e]);
+                o.store(y + (long long)t * P.ldy);
+            }
+        }
+        y += (long long)P.Wo * P.ldy;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            r0[j] = r1[j];
+            r1[j] = r2[j];
+            r2[j] = nx[j];
+        }
+    }
+}
+
 // dx[n,h,w,c] = sum_{r,s} dy[n,ho,wo,c] * w[r,s,c]  with ho*stride - dil + r*dil == h
 template <typename T>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwParams P) {
@@ -184,6 +267,7 @@ struct DwWParams {
     int rows_total;      // N*Ho output rows
     int rows_per_block;
     int tx, log_tx;
+    int gx, bands;  // dw_bwd_weight_s1_kernel: channel blocks, row bands per image
 };
 
 template <typename T, int FAST /* stride 1, dilation 1: sliding 3-column window */>
@@ -287,6 +371,100 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwWParams P) {
     }
 }
 
+// Stride 1 / dilation 1 weight gradient with the register blocking of dw_s1_kernel: a thread
+// owns TW = 4 output columns of one channel vector, walks RB output rows of one image with the
+// 3-row input window in registers (x: 1.5 loads per output instead of 3; branch-free buffer loads,
+// out-of-image = 0), then moves to its next column group.  Block = TX channel vectors x TY column
+// lanes over one band of rows; partials are folded through LDS one tap at a time.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int TW = 4, NCOL = TW + 2;
+    typedef typename Elem<T>::vec_t vec_t;
+    __shared__ float red[256 * VEC];
+    const int lx = threadIdx.x & (P.tx - 1);
+    const int ly = threadIdx.x >> P.log_tx;
+    const int ty = 256 >> P.log_tx;
+    int band, bx;
+    dw_block_to_row(P.gx, band, bx);
+    const int c = (bx * P.tx + lx) * VEC;
+    const bool c_ok = c < P.C;
+    float acc[9][VEC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    const int n = band / P.bands, b = band - n * P.bands;
+    const int ho0 = b * P.rows_per_block;
+    const int ho1 = min(ho0 + P.rows_per_block, P.Ho);
+    const unsigned xrow_bytes = (unsigned)P.W * P.ldx * sizeof(T);
+    const unsigned grow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
+    const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * xrow_bytes;
+    const char* gn = reinterpret_cast<const char*>(P.dy) + (long long)n * P.Ho * grow_bytes;
+    const int nwq = (P.Wo + TW - 1) / TW;
+    if (c_ok) {
+        for (int wq = ly; wq < nwq; wq += ty) {
+            const int wo0 = wq * TW;
+            int voff[NCOL], goff[TW];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 - 1 + j) * P.ldx + c) * (int)sizeof(T);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) goff[t] = ((wo0 + t) * P.ldy + c) * (int)sizeof(T);
+            auto load_row = [&](int ih, Chunk<T>(&dst)[NCOL]) {
+                const bool ok = (unsigned)ih < (unsigned)P.H;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(xn + (long long)(ok ? ih : 0) * xrow_bytes), 0, ok ? xrow_bytes : 0u, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j)
+                    dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
+            };
+            Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], nx[NCOL], gv[TW];
+            load_row(ho0 - 1, r0);
+            load_row(ho0, r1);
+            load_row(ho0 + 1, r2);
+            for (int ho = ho0; ho < ho1; ++ho) {
+                const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(gn + (long long)ho * grow_bytes), 0, grow_bytes, 0x00020000);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)  // columns past Wo are out of range: zero gradient
+                    gv[t].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rg, goff[t], 0, 0));
+                if (ho + 1 < ho1) load_row(ho + 2, nx);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float g = gv[t].get(e);
+                            acc[0 + s][e] = fmaf(g, r0[t + s].get(e), acc[0 + s][e]);
+                            acc[3 + s][e] = fmaf(g, r1[t + s].get(e), acc[3 + s][e]);
+                            acc[6 + s][e] = fmaf(g, r2[t + s].get(e), acc[6 + s][e]);
+                        }
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) {
+                    r0[j] = r1[j];
+                    r1[j] = r2[j];
+                    r2[j] = nx[j];
+                }
+            }
+        }
+    }
+    const int row_w = P.tx * VEC;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[ly * row_w + lx * VEC + e] = acc[t][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < row_w; i += 256) {
+            float a = 0.f;
+            for (int y = 0; y < ty; ++y) a += red[y * row_w + i];
+            const int ch = bx * row_w + i;
+            if (ch < P.C) atomicAdd(P.dw + (long long)t * P.C + ch, a);
+        }
+    }
+}
+
 int check_dw(const bg_dwconv_desc* d, const char* who) {
     BG_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
     BG_CHECK_ARG(dtype_ok(d->dtype), "%s: bad dtype", who);
@@ -297,6 +475,23 @@ int check_dw(const bg_dwconv_desc* d, const char* who) {
                  "%s: C/ld must be multiples of %d", who, vec);
     BG_CHECK_ARG(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride,
                  "%s: Ho/Wo must be ceil(H/stride), ceil(W/stride)", who);
+    return BG_OK;
+}
+
+// stride 1 / dilation 1 launcher shared by forward (flip 0) and data gradient (flip 1)
+int launch_dw_s1(int dtype, DwParams P, int flip, hipStream_t st, const char* who) {
+    static const int k_rb = getenv("BGAMD_DW_RB") ? atoi(getenv("BGAMD_DW_RB")) : 4;  // tuning knob
+    const int cv = P.C / dtype_vec(dtype);
+    BG_CHECK_ARG((long long)P.W * P.ldx * 4 < 0x7fffffffLL, "%s: image row too large", who);
+    P.rb = k_rb < P.Ho ? k_rb : P.Ho;
+    P.bands = (P.Ho + P.rb - 1) / P.rb;
+    P.items = ((P.Wo + 3) / 4) * cv;
+    P.bx = (P.items + 255) / 256;
+    const long long blocks = (long long)P.N * P.bands * P.bx;
+    BG_CHECK_ARG(blocks <= 0x7fffffffLL, "%s: grid too large", who);
+    if (flip) BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+    else BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+    BG_CHECK_LAUNCH(who);
     return BG_OK;
 }
 
@@ -311,6 +506,8 @@ extern "C" int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const vo
     hipStream_t st = (hipStream_t)stream;
     const int cv = d->C / dtype_vec(d->dtype);
     const int sd = d->stride * 10 + d->dil;
+    static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
+    if (sd == 11 && !old11) return launch_dw_s1(d->dtype, P, 0, st, "dw_s1_kernel");
     if (sd == 11 || sd == 12 || sd == 21) {
         P.items = ((d->Wo + 3) / 4) * cv;
         P.bx = (P.items + 255) / 256;
@@ -343,6 +540,8 @@ extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, co
         // stride 1: the data gradient is the same stencil with the taps reversed
         // (dy plays the input, dx the output; both are H x W)
         DwParams Q{dy, w, dx, d->N, d->H, d->W, d->C, d->H, d->W, 1, d->dil, d->ldy, d->ldx, 0, 0};
+        static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
+        if (d->dil == 1 && !old11) return launch_dw_s1(d->dtype, Q, 1, st, "dw_s1_kernel(flip)");
         Q.items = ((d->W + 3) / 4) * cv;
         Q.bx = (Q.items + 255) / 256;
         BG_CHECK_ARG(rows * Q.bx <= 0x7fffffffLL, "bg_dwconv3x3_bwd_data: grid too large");
@@ -376,6 +575,22 @@ extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, c
     P.tx = best;
     P.log_tx = best == 16 ? 4 : (best == 32 ? 5 : 6);
     const int gx = (cv + best - 1) / best;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
+    if (d->stride == 1 && d->dil == 1 && !old11) {
+        static const int k_rb = getenv("BGAMD_DWW_RB") ? atoi(getenv("BGAMD_DWW_RB")) : 4;  // tuning knob
+        BG_CHECK_ARG((long long)d->W * d->ldx * 4 < 0x7fffffffLL && (long long)d->Wo * d->ldy * 4 < 0x7fffffffLL,
+                     "bg_dwconv3x3_bwd_weight: image row too large");
+        P.rows_per_block = k_rb < d->Ho ? k_rb : d->Ho;
+        P.bands = (d->Ho + P.rows_per_block - 1) / P.rows_per_block;
+        P.gx = gx;
+        const long long blocks = (long long)gx * d->N * P.bands;
+        BG_CHECK_ARG(blocks <= 0x7fffffffLL, "bg_dwconv3x3_bwd_weight: grid too large");
+        BG_DISPATCH_DTYPE(d->dtype, T,
+                          hipLaunchKernelGGL((dw_bwd_weight_s1_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+        BG_CHECK_LAUNCH("dw_bwd_weight_s1_kernel");
+        return BG_OK;
+    }
     P.rows_total = d->N * d->Ho;
     // ~1536 blocks in total; each block at least one output row
     int gy = 1536 / gx;
@@ -383,7 +598,6 @@ extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, c
     if (gy > P.rows_total) gy = P.rows_total;
     P.rows_per_block = (P.rows_total + gy - 1) / gy;
     gy = (P.rows_total + P.rows_per_block - 1) / P.rows_per_block;
-    hipStream_t st = (hipStream_t)stream;
     if (d->stride == 1 && d->dil == 1)
         BG_DISPATCH_DTYPE(d->dtype, T,
                           hipLaunchKernelGGL((dw_bwd_weight_kernel<T, 1>), dim3(gx, (unsigned)gy), dim3(256), 0, st, P));

@@ -21,6 +21,11 @@ struct Tiling {
     int gy;
 };
 
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 inline Tiling make_tiling(int dtype, int C, long long rows_per_group, int groups, int min_rows_per_thread,
                           int target_blocks) {
     const int cv = C / dtype_vec(dtype);
@@ -35,6 +40,7 @@ inline Tiling make_tiling(int dtype, int C, long long rows_per_group, int groups
     t.gx = (cv + best - 1) / best;
     const int ty = 256 / best;
     long long want = target_blocks / ((long long)t.gx * groups);
+    if (want >= 8) want = want / 8 * 8;  // the grid is gx * roundup8(gy) blocks (BG_BLOCK_COORDS): stay within the target
     if (want < 1) want = 1;
     long long rpb = (rows_per_group + want - 1) / want;
     const long long min_rpb = (long long)ty * min_rows_per_thread;
@@ -51,6 +57,28 @@ inline Tiling make_tiling(int dtype, int C, long long rows_per_group, int groups
     return t;
 }
 
+// Block -> (channel block bx, row block by).  The gx channel blocks of one row range touch the same
+// 128-byte lines whenever the row pitch is not a multiple of 128 B (C = 728): consecutive block ids go
+// to different XCDs, so the ids are dealt such that those gx blocks land on ONE XCD (one L2 fetches /
+// merges the shared lines).  The grid is gx * roundup8(gy) blocks; surplus blocks exit.
+#define BG_BLOCK_COORDS(P, bx, by)                         \
+    int bx, by;                                            \
+    {                                                      \
+        const int id_ = blockIdx.x, slot_ = id_ >> 3;      \
+        const int q_ = slot_ / (P).gx;                     \
+        bx = slot_ - q_ * (P).gx;                          \
+        by = q_ * 8 + (id_ & 7);                           \
+        if (by >= (P).gy) return;                          \
+    }
+inline unsigned xcd_grid(int gx, int gy) { return (unsigned)(gx * ((gy + 7) / 8 * 8)); }
+
+// scale/shift of the normalisation, written ONCE so that the backward kernels that recompute the
+// pre-activation sign (y not re-read) evaluate bit-identical arithmetic to the forward pass
+__device__ __forceinline__ void norm_affine(float gamma, float beta, float mean, float rstd, float& sc, float& sh) {
+    sc = gamma * rstd;
+    sh = fmaf(-(mean * gamma), rstd, beta);
+}
+
 // ------------------------------------------------------------ column reduce --
 enum { RED_STATS = 0, RED_BWD = 1, RED_COLSUM = 2 };
 
@@ -61,6 +89,8 @@ struct RedParams {
     int lda, ldb, ldc;
     const float* mean;
     const float* rstd;
+    const float* gamma;  // bwd with b == NULL: LeakyReLU slope from the recomputed pre-activation
+    const float* beta;
     int act;
     long long rows_per_group;
     int rows_per_block;
@@ -70,6 +100,7 @@ struct RedParams {
     double* o2;
     float* of;  // colsum output
     float scale;
+    int gx, gy;
 };
 
 template <typename T, int MODE>
@@ -80,10 +111,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
     const int lx = threadIdx.x & (P.tx - 1);
     const int ly = threadIdx.x >> P.log_tx;
     const int ty = 256 >> P.log_tx;
-    const int c = (blockIdx.x * P.tx + lx) * VEC;
+    BG_BLOCK_COORDS(P, bx, by);
+    const int c = (bx * P.tx + lx) * VEC;
     const bool c_ok = c < P.C;
     const int g = blockIdx.z;
-    const long long r0 = (long long)blockIdx.y * P.rows_per_block;
+    const long long r0 = (long long)by * P.rows_per_block;
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long gbase = (long long)g * P.rows_per_group;
@@ -91,19 +123,20 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
     float s1[VEC], s2[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
-    float mu[VEC], rs[VEC];
+    float mu[VEC], rs[VEC], sc[VEC], sh[VEC];
     if (MODE == RED_BWD && c_ok) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             mu[e] = P.mean ? P.mean[(long long)g * P.C + c + e] : 0.f;
             rs[e] = P.rstd ? P.rstd[(long long)g * P.C + c + e] : 1.f;
+            norm_affine(P.gamma ? P.gamma[c + e] : 1.f, P.beta ? P.beta[c + e] : 0.f, mu[e], rs[e], sc[e], sh[e]);
         }
     }
     if (c_ok) {
         const T* a = reinterpret_cast<const T*>(P.a) + (gbase + r0 + ly) * P.lda + c;
-        const T* b = reinterpret_cast<const T*>(P.b) + (gbase + r0 + ly) * P.ldb + c;
+        const T* b = P.b ? reinterpret_cast<const T*>(P.b) + (gbase + r0 + ly) * P.ldb + c : nullptr;
         const T* cc = P.c ? reinterpret_cast<const T*>(P.c) + (gbase + r0 + ly) * P.ldc + c : nullptr;
-        const long long sa = (long long)ty * P.lda, sb = (long long)ty * P.ldb, sc = (long long)ty * P.ldc;
+        const long long sa = (long long)ty * P.lda, sb = (long long)ty * P.ldb, s_c = (long long)ty * P.ldc;
 #pragma unroll 4
         for (long long r = r0 + ly; r < r1; r += ty) {
             Chunk<T> va;
@@ -121,12 +154,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
                 for (int e = 0; e < VEC; ++e) s1[e] += va.get(e);
             } else {
                 Chunk<T> vy, vx;
-                if (P.act) { vy.load(b); b += sb; }
-                if (cc) { vx.load(cc); cc += sc; }
+                if (P.act && b) { vy.load(b); b += sb; }
+                if (cc) { vx.load(cc); cc += s_c; }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float gg = va.get(e);
-                    if (P.act) gg *= (vy.get(e) > 0.f ? 1.f : LRELU_SLOPE);
+                    if (P.act) gg *= ((b ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : LRELU_SLOPE);
                     s1[e] += gg;
                     if (cc) s2[e] = fmaf(gg, (vx.get(e) - mu[e]) * rs[e], s2[e]);
                 }
@@ -147,7 +180,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
         const int col = i - st * row_w;
         float acc = 0.f;
         for (int y = 0; y < ty; ++y) acc += red[(st * ty + y) * row_w + col];
-        const int ch = blockIdx.x * row_w + col;
+        const int ch = bx * row_w + col;
         if (ch < P.C) {
             const long long o = (long long)g * P.C + ch;
             if (MODE == RED_COLSUM) atomicAdd(P.of + o, acc * P.scale);
@@ -159,10 +192,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
 
 template <int MODE>
 int launch_colreduce(int dtype, RedParams P, int groups, hipStream_t st, const char* who) {
-    const Tiling t = make_tiling(dtype, P.C, P.rows_per_group, groups, 16, 1536);
-    P.tx = t.tx; P.log_tx = t.log_tx; P.rows_per_block = t.rows_per_block;
+    static const int k_rows = env_int("BGAMD_RED_ROWS", 16), k_blocks = env_int("BGAMD_RED_BLOCKS", 1024);  // tuning knobs
+    const Tiling t = make_tiling(dtype, P.C, P.rows_per_group, groups, k_rows, k_blocks);
+    P.tx = t.tx; P.log_tx = t.log_tx; P.rows_per_block = t.rows_per_block; P.gx = t.gx; P.gy = t.gy;
     BG_CHECK_ARG(groups <= 65535, "%s: too many groups", who);
-    dim3 grid(t.gx, t.gy, (unsigned)groups);
+    dim3 grid(xcd_grid(t.gx, t.gy), 1, (unsigned)groups);
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, st, P));
     BG_CHECK_LAUNCH(who);
     return BG_OK;
@@ -247,6 +281,7 @@ struct EwParams {
     float eps, momentum;
     float* rmean; float* rvar;      // running statistics (batch norm, groups == 1) or NULL
     float* mean_out; float* rstd_out;
+    int gx, gy;
 };
 
 template <typename T>
@@ -255,10 +290,11 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     const int lx = threadIdx.x & (P.tx - 1);
     const int ly = threadIdx.x >> P.log_tx;
     const int ty = 256 >> P.log_tx;
-    const int c = (blockIdx.x * P.tx + lx) * VEC;
+    BG_BLOCK_COORDS(P, bx, by);
+    const int c = (bx * P.tx + lx) * VEC;
     if (c >= P.C) return;
     const int g = blockIdx.z;
-    const long long r0 = (long long)blockIdx.y * P.rows_per_block;
+    const long long r0 = (long long)by * P.rows_per_block;
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
@@ -267,7 +303,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
         // every thread derives the affine of its own channels from the fp64 sums (a few flops);
         // the first row-block of each group also publishes mean / rstd for the backward pass
         // and applies the BatchNorm running-statistics update -- no separate finalize launch
-        const bool publish = blockIdx.y == 0 && ly == 0;
+        const bool publish = by == 0 && ly == 0;
         const double n = (double)P.rows_per_group;
         const double inv_n = 1.0 / n;  // one fp64 division per thread; the rest is fp64 mul/add + one fp32 rsqrt
 #pragma unroll
@@ -279,8 +315,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
             const float r = rsqrtf((float)var + P.eps);
             const float gm = P.gamma ? P.gamma[c + e] : 1.f;
             const float bt = P.beta ? P.beta[c + e] : 0.f;
-            sc[e] = gm * r;
-            sh[e] = bt - (float)m * gm * r;
+            norm_affine(gm, bt, (float)m, r, sc[e], sh[e]);
             if (publish) {
                 P.mean_out[i] = (float)m;
                 P.rstd_out[i] = r;
@@ -330,9 +365,10 @@ struct EwBwdParams {
     int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
     // fused finalize when s1 != NULL: coefficients from the fp64 sums, dgamma/dbeta by the first row-block
     const double* s1; const double* s2;
-    const float* gamma; const float* mean; const float* rstd;
+    const float* gamma; const float* beta; const float* mean; const float* rstd;
     float* dgamma; float* dbeta;
     int train; int groups;
+    int gx, gy;
 };
 
 template <typename T>
@@ -341,15 +377,17 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
     const int lx = threadIdx.x & (P.tx - 1);
     const int ly = threadIdx.x >> P.log_tx;
     const int ty = 256 >> P.log_tx;
-    const int c = (blockIdx.x * P.tx + lx) * VEC;
+    BG_BLOCK_COORDS(P, bx, by);
+    const int c = (bx * P.tx + lx) * VEC;
     if (c >= P.C) return;
     const int g = blockIdx.z;
-    const long long r0 = (long long)blockIdx.y * P.rows_per_block;
+    const long long r0 = (long long)by * P.rows_per_block;
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
     const bool useB = P.s1 ? (P.train != 0) : (P.A && P.B);
-    float ca[VEC], cb[VEC], cc[VEC];
+    float ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
+    const bool sign_from_x = P.act && !P.y;  // no residual: the LeakyReLU branch follows from x*scale+shift
     if (P.s1) {
         const float inv_n = 1.f / (float)P.rows_per_group;
 #pragma unroll
@@ -357,12 +395,13 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
             const long long i = (long long)g * P.C + c + e;
             const float gm = P.gamma ? P.gamma[c + e] : 1.f;
             const float r = P.rstd[i], m = P.mean[i];
+            norm_affine(gm, P.beta ? P.beta[c + e] : 0.f, m, r, sc[e], sh[e]);
             const float a1 = (float)P.s1[i] * inv_n, a2 = (float)P.s2[i] * inv_n;  // means of g and g*xhat
             ca[e] = gm * r;
             cb[e] = P.train ? -gm * r * r * a2 : 0.f;
             cc[e] = P.train ? gm * r * (r * a2 * m - a1) : 0.f;
         }
-        if (P.dgamma && blockIdx.y == 0 && ly == 0 && g == 0) {
+        if (P.dgamma && by == 0 && ly == 0 && g == 0) {
             // parameter gradients: sum over groups (one thread per channel, once)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -379,15 +418,17 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const long long so = (long long)g * P.C + c + e;
+            sc[e] = 1.f;
+            sh[e] = 0.f;
             ca[e] = P.A ? P.A[so] : 1.f;
             cb[e] = useB ? P.B[so] : 0.f;
             cc[e] = useB ? P.Cc[so] : 0.f;
         }
     }
     const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;
-    const T* y = P.act ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
+    const T* y = (P.act && P.y) ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
     const bool scaleA = P.s1 || P.A;
-    const T* x = useB ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
+    const T* x = (useB || sign_from_x) ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
     T* dx = P.dx ? reinterpret_cast<T*>(P.dx) + row0 * P.lddx + c : nullptr;
     T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + row0 * P.lddres + c : nullptr;
     const long long s_dy = (long long)ty * P.lddy, s_y = (long long)ty * P.ldy, s_x = (long long)ty * P.ldx;
@@ -403,7 +444,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             gg[e] = vg.get(e);
-            if (P.act) gg[e] *= (vy.get(e) > 0.f ? 1.f : LRELU_SLOPE);
+            if (P.act) gg[e] *= ((y ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : LRELU_SLOPE);
         }
         if (dres) {
 #pragma unroll
@@ -466,23 +507,26 @@ extern "C" int bg_colsum(int32_t dtype, const void* x, int32_t ldx, int64_t rows
 }
 
 extern "C" int bg_norm_act_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
-                                      const void* x, int32_t ldx, const float* mean, const float* rstd, int64_t rows,
-                                      int32_t C, int32_t groups, int32_t act, double* s1, double* s2, void* stream) {
+                                      const void* x, int32_t ldx, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, int64_t rows, int32_t C, int32_t groups,
+                                      int32_t act, double* s1, double* s2, void* stream) {
     int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_reduce");
     if (rc) return rc;
     CHECK_LD(lddy, "bg_norm_act_bwd_reduce");
     BG_CHECK_ARG(dy && s1 && aligned16(dy), "bg_norm_act_bwd_reduce: null/unaligned pointer");
-    if (act) {
-        BG_CHECK_ARG(y && aligned16(y), "bg_norm_act_bwd_reduce: act needs y");
+    if (act && y) {
+        BG_CHECK_ARG(aligned16(y), "bg_norm_act_bwd_reduce: unaligned y");
         CHECK_LD(ldy, "bg_norm_act_bwd_reduce");
     }
+    BG_CHECK_ARG(!act || y || x, "bg_norm_act_bwd_reduce: act needs y, or x to recompute the pre-activation");
     if (x) {
         BG_CHECK_ARG(aligned16(x) && s2 && mean && rstd, "bg_norm_act_bwd_reduce: x needs mean/rstd/s2");
         CHECK_LD(ldx, "bg_norm_act_bwd_reduce");
     }
     RedParams P{};
     P.a = dy; P.lda = lddy; P.b = y; P.ldb = ldy; P.c = x; P.ldc = ldx;
-    P.mean = mean; P.rstd = rstd; P.act = act; P.C = C; P.rows_per_group = rows / groups;
+    P.mean = mean; P.rstd = rstd; P.gamma = gamma; P.beta = beta; P.act = act; P.C = C;
+    P.rows_per_group = rows / groups;
     P.o1 = s1; P.o2 = x ? s2 : nullptr;
     return launch_colreduce<RED_BWD>(dtype, P, groups, (hipStream_t)stream, "bg_norm_act_bwd_reduce");
 }
@@ -540,7 +584,8 @@ extern "C" int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const 
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd: too many groups");
     EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
                nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
+    P.gx = t.gx; P.gy = t.gy;
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_fwd_kernel");
     return BG_OK;
@@ -574,8 +619,9 @@ extern "C" int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy
     const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply: too many groups");
     EwBwdParams P{dy, lddy, y, ldy, x, ldx, A, B, Cc, dx, lddx, dres, lddres, C, rows / groups, t.rows_per_block, act,
-                  t.tx, t.log_tx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, groups};
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
+                  t.tx, t.log_tx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, groups};
+    P.gx = t.gx; P.gy = t.gy;
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel");
     return BG_OK;
@@ -600,11 +646,13 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
     }
     // fewer, longer-running threads than the plain apply kernel: each thread first derives its
     // channels' affine from the sums, which must be amortised over the rows it then walks
-    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 16, 2048);
+    static const int k_rows = env_int("BGAMD_EWS_ROWS", 16), k_blocks = env_int("BGAMD_EWS_BLOCKS", 1024);  // tuning knobs
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks);
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd_stats: too many groups");
     EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
                sum, sumsq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd};
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
+    P.gx = t.gx; P.gy = t.gy;
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_fwd_kernel(stats)");
     return BG_OK;
@@ -612,8 +660,9 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
 
 extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
                                            const void* x, int32_t ldx, const double* s1, const double* s2,
-                                           const float* gamma, const float* mean, const float* rstd, int32_t train,
-                                           float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
+                                           const float* gamma, const float* beta, const float* mean,
+                                           const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx,
+                                           int32_t lddx, void* dres,
                                            int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
                                            void* stream) {
     int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_apply_stats");
@@ -623,8 +672,8 @@ extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_
     BG_CHECK_ARG(dy && x && s1 && s2 && mean && rstd && aligned16(dy) && aligned16(x) && (dx || dres || dgamma),
                  "bg_norm_act_bwd_apply_stats: null/unaligned pointer");
     BG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "bg_norm_act_bwd_apply_stats: dgamma/dbeta in pairs");
-    if (act) {
-        BG_CHECK_ARG(y && aligned16(y), "bg_norm_act_bwd_apply_stats: act needs y");
+    if (act && y) {  // y == NULL: the LeakyReLU branch is recomputed from x*scale+shift (no residual)
+        BG_CHECK_ARG(aligned16(y), "bg_norm_act_bwd_apply_stats: unaligned y");
         CHECK_LD(ldy, "bg_norm_act_bwd_apply_stats");
     }
     if (dx) {
@@ -635,11 +684,13 @@ extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_
         BG_CHECK_ARG(aligned16(dres), "bg_norm_act_bwd_apply_stats: unaligned dres");
         CHECK_LD(lddres, "bg_norm_act_bwd_apply_stats");
     }
-    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 16, 2048);
+    static const int k_rows = env_int("BGAMD_EWS_ROWS", 16), k_blocks = env_int("BGAMD_EWS_BLOCKS", 1024);  // tuning knobs
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks);
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply_stats: too many groups");
     EwBwdParams P{dy, lddy, y, ldy, x, ldx, nullptr, nullptr, nullptr, dx, lddx, dres, lddres, C, rows / groups,
-                  t.rows_per_block, act, t.tx, t.log_tx, s1, s2, gamma, mean, rstd, dgamma, dbeta, train, groups};
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(t.gx, t.gy, groups), dim3(256), 0,
+                  t.rows_per_block, act, t.tx, t.log_tx, s1, s2, gamma, beta, mean, rstd, dgamma, dbeta, train, groups};
+    P.gx = t.gx; P.gy = t.gy;
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel(stats)");
     return BG_OK;

@@ -188,6 +188,44 @@ __global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int N, int C, int 
     }
 }
 
+// Fast forms (16-byte aligned rows, Cp and ld multiples of the 16-byte vector): one pixel per
+// thread, channel loads coalesced across the wave, 16-byte packed stores / loads on the NHWC side.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_vec_kernel(const float* src, T* dst, int C, int HW, int Cp, int ldd) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int n = blockIdx.y;
+    const float* s = src + (long long)n * C * HW + p;
+    T* d = dst + ((long long)n * HW + p) * ldd;
+    for (int c0 = 0; c0 < Cp; c0 += VEC) {
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = (c0 + e < C) ? __builtin_nontemporal_load(s + (long long)(c0 + e) * HW) : 0.f;
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, v[e]);
+        o.store(d + c0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_vec_kernel(const T* src, int lds, float* dst, int C, int HW) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int n = blockIdx.y;
+    const T* s = src + ((long long)n * HW + p) * lds;
+    float* d = dst + (long long)n * C * HW + p;
+    for (int c0 = 0; c0 < C; c0 += VEC) {
+        Chunk<T> v;
+        v.load(s + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (c0 + e < C) __builtin_nontemporal_store(v.get(e), d + (long long)(c0 + e) * HW);
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* src, int lds, float* dst, int N, int C, int HW) {
     const long long total = (long long)N * HW;
@@ -300,6 +338,13 @@ extern "C" int bg_nchw_to_nhwc(int32_t dst_dtype, const float* src, void* dst, i
     BG_CHECK_ARG(dtype_ok(dst_dtype) && src && dst && N > 0 && C > 0 && HW > 0 && Cp >= C && ldd >= Cp,
                  "bg_nchw_to_nhwc: bad args");
     const long long total = (long long)N * HW;
+    const int vec = dtype_vec(dst_dtype);
+    if (aligned16(dst) && Cp % vec == 0 && ldd % vec == 0 && N <= 65535) {
+        BG_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_vec_kernel<T>), dim3((HW + 255) / 256, N), dim3(256),
+                                                           0, (hipStream_t)stream, src, (T*)dst, C, HW, Cp, ldd));
+        BG_CHECK_LAUNCH("nchw_to_nhwc_vec_kernel");
+        return BG_OK;
+    }
     BG_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
                                                        (hipStream_t)stream, src, (T*)dst, N, C, HW, Cp, ldd));
     BG_CHECK_LAUNCH("nchw_to_nhwc_kernel");
@@ -310,6 +355,14 @@ extern "C" int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, 
                                int32_t HW, void* stream) {
     BG_CHECK_ARG(dtype_ok(src_dtype) && src && dst && N > 0 && C > 0 && HW > 0 && lds >= C, "bg_nhwc_to_nchw: bad args");
     const long long total = (long long)N * HW;
+    const int vec = dtype_vec(src_dtype);
+    // the vector form reads whole 16-byte chunks: the row must hold them (lds >= C rounded up)
+    if (aligned16(src) && lds % vec == 0 && lds >= (C + vec - 1) / vec * vec && N <= 65535) {
+        BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_vec_kernel<T>), dim3((HW + 255) / 256, N), dim3(256),
+                                                           0, (hipStream_t)stream, (const T*)src, lds, dst, C, HW));
+        BG_CHECK_LAUNCH("nhwc_to_nchw_vec_kernel");
+        return BG_OK;
+    }
     BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
                                                        (hipStream_t)stream, (const T*)src, lds, dst, N, C, HW));
     BG_CHECK_LAUNCH("nhwc_to_nchw_kernel");

@@ -289,19 +289,24 @@ class NormActFn(torch.autograd.Function):
                    out.data_ptr(), c, None, 0, rows, c, groups, act)
             return (out if need_dx else None, out if need_res else None) + (None,) * 13
         want_affine_grads = gslot is not None and gslot.param.requires_grad
+        gptr = None if gslot is None else arena.master_ptr(gslot)
+        bptr = None if bslot is None else arena.master_ptr(bslot)
+        # without a residual the LeakyReLU branch follows from x and the saved statistics: the
+        # backward kernels recompute it (the forward kernel's arithmetic) instead of re-reading y
+        yptr = None if (batch_stats and not has_res) else y.data_ptr()
         if need_dx or want_affine_grads:
             s = _f64(2, groups, c, device=dev)
-            L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
-                   mean.data_ptr(), rstd.data_ptr(), rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
+            L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), yptr, c, x.data_ptr(), ld_of(x),
+                   mean.data_ptr(), rstd.data_ptr(), gptr, bptr, rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
             dg = db = None
             if want_affine_grads:
                 arena.ensure_grad(gslot)
                 arena.ensure_grad(bslot)
                 dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
             # finalize (coefficients, dgamma/dbeta) is folded into the apply kernel
-            L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, x.data_ptr(), ld_of(x),
-                   s[0].data_ptr(), s[1].data_ptr(), None if gslot is None else arena.master_ptr(gslot), mean.data_ptr(),
-                   rstd.data_ptr(), 1 if batch_stats else 0, dg, db, L.ptr(dx), c, L.ptr(dres), c, rows, c, groups, act)
+            L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), yptr, c, x.data_ptr(), ld_of(x),
+                   s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
+                   1 if batch_stats else 0, dg, db, L.ptr(dx), c, L.ptr(dres), c, rows, c, groups, act)
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None, None, 0,
                    dres.data_ptr(), c, rows, c, groups, act)

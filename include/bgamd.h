@@ -145,10 +145,13 @@ int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, const doubl
                           float* running_var, float* mean, float* rstd, const void* res, int32_t ldres, void* y,
                           int32_t ldy, int64_t rows, int32_t C, int32_t groups, int32_t act, void* stream);
 /* Backward pass 1: g = dy * act'(y);  s1[g,c] += sum g, s2[g,c] += sum g*xhat
- * (fp64, caller zeroes) with xhat = (x-mean)*rstd. */
+ * (fp64, caller zeroes) with xhat = (x-mean)*rstd.  y == NULL with act != 0 (layers WITHOUT a
+ * residual): the LeakyReLU branch is taken from the recomputed pre-activation
+ * x*(gamma*rstd) + (beta - mean*gamma*rstd) -- the forward kernel's own arithmetic -- so the
+ * activated tensor is not read again (gamma/beta NULL = 1/0). */
 int bg_norm_act_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
-                           int32_t ldx, const float* mean, const float* rstd, int64_t rows, int32_t C,
-                           int32_t groups, int32_t act, double* s1, double* s2, void* stream);
+                           int32_t ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int64_t rows, int32_t C, int32_t groups, int32_t act, double* s1, double* s2, void* stream);
 /* Coefficients of pass 2 (dx = A*g + B*x + Cc) and dgamma += sum_g s2, dbeta += sum_g s1
  * (dgamma/dbeta/gamma may be NULL).  train != 0: batch/instance statistics
  * (full formula); train == 0: dx = scale*g. */
@@ -163,12 +166,13 @@ int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const voi
                           void* stream);
 
 /* bg_norm_bwd_finalize + bg_norm_act_bwd_apply in ONE launch: coefficients from s1/s2 per thread,
- * dgamma += sum_g s2 and dbeta += sum_g s1 by the first row-block (both may be NULL). */
+ * dgamma += sum_g s2 and dbeta += sum_g s1 by the first row-block (both may be NULL).
+ * y == NULL with act != 0: as in bg_norm_act_bwd_reduce. */
 int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
-                                int32_t ldx, const double* s1, const double* s2, const float* gamma, const float* mean,
-                                const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx, int32_t lddx,
-                                void* dres, int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
-                                void* stream);
+                                int32_t ldx, const double* s1, const double* s2, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, int32_t train, float* dgamma, float* dbeta,
+                                void* dx, int32_t lddx, void* dres, int32_t lddres, int64_t rows, int32_t C,
+                                int32_t groups, int32_t act, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Resampling / pooling / layout (deeplab.py:375,379,663 bilinear

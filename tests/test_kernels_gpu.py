@@ -276,7 +276,7 @@ def test_norm_act(dtype, mode, act, with_res):
     else:
         s1, s2 = f64(groups, c), f64(groups, c)
         L.call("bg_norm_act_bwd_reduce", dtc, gv.data_ptr(), c, yb.data_ptr(), c, xv.data_ptr(), c, mean.data_ptr(),
-               rstd.data_ptr(), rows, c, groups, act, s1.data_ptr(), s2.data_ptr())
+               rstd.data_ptr(), None, None, rows, c, groups, act, s1.data_ptr(), s2.data_ptr())
         aff = mode in ("batch", "eval")
         L.call("bg_norm_bwd_finalize", s1.data_ptr(), s2.data_ptr(), rows // groups, groups, c,
                g_d.data_ptr() if aff else None, mean.data_ptr(), rstd.data_ptr(), 0 if mode == "eval" else 1,
@@ -503,14 +503,14 @@ def test_norm_act_fused_finalize_matches_split(dtype, mode):
                    y.data_ptr(), c, rows, c, groups, 1)
         s1, s2 = f64(groups, c), f64(groups, c)
         L.call("bg_norm_act_bwd_reduce", dtc, gv.data_ptr(), c, y.data_ptr(), c, xv.data_ptr(), c, mean.data_ptr(),
-               rstd.data_ptr(), rows, c, groups, 1, s1.data_ptr(), s2.data_ptr())
+               rstd.data_ptr(), None, None, rows, c, groups, 1, s1.data_ptr(), s2.data_ptr())
         dx = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
         dres = torch.zeros_like(dx)
         dg, db = (f32(c), f32(c)) if aff else (None, None)
         if fused:
             L.call("bg_norm_act_bwd_apply_stats", dtc, gv.data_ptr(), c, y.data_ptr(), c, xv.data_ptr(), c, s1.data_ptr(),
-                   s2.data_ptr(), L.ptr(gamma), mean.data_ptr(), rstd.data_ptr(), 1, L.ptr(dg), L.ptr(db), dx.data_ptr(), c,
-                   dres.data_ptr(), c, rows, c, groups, 1)
+                   s2.data_ptr(), L.ptr(gamma), L.ptr(beta), mean.data_ptr(), rstd.data_ptr(), 1, L.ptr(dg), L.ptr(db),
+                   dx.data_ptr(), c, dres.data_ptr(), c, rows, c, groups, 1)
         else:
             A, B, Cc = f32(groups, c), f32(groups, c), f32(groups, c)
             L.call("bg_norm_bwd_finalize", s1.data_ptr(), s2.data_ptr(), rows // groups, groups, c, L.ptr(gamma),
@@ -524,3 +524,45 @@ def test_norm_act_fused_finalize_matches_split(dtype, mode):
     for k in a:
         if a[k] is not None:
             assert_close(b[k], a[k], 2e-5 if dtype == torch.float32 else 1e-2, k)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["batch", "instance"])
+def test_norm_act_bwd_sign_recomputed_from_x(dtype, mode):
+    """Layers without a residual: bg_norm_act_bwd_reduce / _apply_stats called with y == NULL take
+    the LeakyReLU branch from the recomputed pre-activation; results must be IDENTICAL (bit for bit)
+    to the calls that read the stored activation."""
+    n, h, w, c = 4, 13, 10, 48
+    x = (rnd((n, c, h, w), 41, dtype, 2.0) + 0.3).to(dtype).float()
+    go = rnd((n, c, h, w), 43, dtype)
+    rows, groups, dtc = n * h * w, (n if mode == "instance" else 1), L.dt(dtype)
+    (xb, xv), (gb, gv) = to_nhwc(x, dtype), to_nhwc(go, dtype)
+    aff = mode == "batch"
+    gamma = (torch.rand(c) - 0.3).to(DEV) if aff else None      # negative gammas included
+    beta = (torch.randn(c) * 0.2).to(DEV) if aff else None
+    f32 = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    f64 = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.float64)  # noqa: E731
+    s, ss = f64(groups, c), f64(groups, c)
+    L.call("bg_norm_stats", dtc, xv.data_ptr(), rows, c, c, groups, s.data_ptr(), ss.data_ptr())
+    mean, rstd = f32(groups, c), f32(groups, c)
+    y = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+    L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), c, s.data_ptr(), ss.data_ptr(), L.ptr(gamma), L.ptr(beta), 1e-5, 0.1,
+           None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, y.data_ptr(), c, rows, c, groups, 1)
+    out = {}
+    for with_y in (True, False):
+        yp = y.data_ptr() if with_y else None
+        s1, s2 = f64(groups, c), f64(groups, c)
+        L.call("bg_norm_act_bwd_reduce", dtc, gv.data_ptr(), c, yp, c, xv.data_ptr(), c, mean.data_ptr(), rstd.data_ptr(),
+               L.ptr(gamma), L.ptr(beta), rows, c, groups, 1, s1.data_ptr(), s2.data_ptr())
+        dx = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+        dg, db = (f32(c), f32(c)) if aff else (None, None)
+        L.call("bg_norm_act_bwd_apply_stats", dtc, gv.data_ptr(), c, yp, c, xv.data_ptr(), c, s1.data_ptr(), s2.data_ptr(),
+               L.ptr(gamma), L.ptr(beta), mean.data_ptr(), rstd.data_ptr(), 1, L.ptr(dg), L.ptr(db), dx.data_ptr(), c, None, 0,
+               rows, c, groups, 1)
+        out[with_y] = (dx.float().cpu(), None if dg is None else dg.cpu(), None if db is None else db.cpu())
+    # block-reduction order is fixed, only the fp64 atomics' arrival order varies: exact for dx up to that
+    assert_close(out[False][0], out[True][0], 1e-6, "dx")
+    assert (y.float() > 0).sum().item() not in (0, y.numel())
+    if aff:
+        assert_close(out[False][1], out[True][1], 1e-6, "dgamma")
+        assert_close(out[False][2], out[True][2], 1e-6, "dbeta")
