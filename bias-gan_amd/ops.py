@@ -83,6 +83,56 @@ def _e32(*shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+# ------------------------------------------------------- weight gradients on a second stream
+# In a backward pass the data-gradient chain is the critical path; the weight gradients hang off it
+# and nothing downstream reads them before the optimiser.  They are issued on a second HIP stream so
+# that their workgroups fill the tails and ramps of the (short) kernels of the chain.  The stream is
+# joined back into the caller's stream when the autograd engine finishes the pass (queue_callback),
+# so .grad is ordered like any other result of backward().  BGAMD_NO_WGRAD_STREAM=1 disables.
+import os as _os
+
+_WG_STREAMS = {}
+_WG_PENDING = set()
+_WG_ENABLED = not _os.environ.get("BGAMD_NO_WGRAD_STREAM")
+
+
+class _WgradStream:
+    def __init__(self, dev, *tensors):
+        self.dev, self.tensors = dev, tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not _WG_ENABLED or L.PROFILE is not None:   # the profile step times ONE kernel per event pair
+            return self
+        key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        side = _WG_STREAMS.get(key)
+        if side is None:
+            side = _WG_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        if key not in _WG_PENDING:
+            _WG_PENDING.add(key)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wgrad_join(key=None):
+    """Make the current stream wait for the weight-gradient stream(s)."""
+    for k in ([key] if key is not None else list(_WG_STREAMS)):
+        side = _WG_STREAMS.get(k)
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
+        _WG_PENDING.discard(k)
+
+
 # ------------------------------------------------------------------ layout boundary
 class ToInternal(torch.autograd.Function):
     """NCHW fp32 (module boundary, as the reference passes tensors) -> NHWC compute dtype."""
@@ -178,7 +228,8 @@ class Conv2dFn(torch.autograd.Function):
             if bslot is not None and ctx.needs_input_grad[2]:
                 arena.ensure_grad(bslot)
                 dbias = arena.grad_ptr(bslot)
-            L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
+            with _WgradStream(xdev, x, g):
+                L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
         return dx, None, None, None, None, None, None, None, None, None
 
 
@@ -213,7 +264,8 @@ class DwConv3x3Fn(torch.autograd.Function):
             (x,) = ctx.saved_tensors
             arena.ensure_grad(wslot)
             desc = L.DwDesc(L.dt(xdtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(g))
-            L.call("bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
+            with _WgradStream(xdev, x, g):
+                L.call("bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
         return dx, None, None, None, None, None
 
 
