@@ -266,6 +266,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
     Chunk<T> ra[NPASS], rb[NPASS];
     const int ksteps_per_tap = (P.CK + BK - 1) / BK;
     const int KT = RS * ksteps_per_tap;
+    // The last K-step of a tap may reach past the CK real channels of a pixel.  The packed weights
+    // are zero there, but the activation lanes are whatever sits behind the row (the next pixel,
+    // or the never-written pad lanes of a row whose pixel stride is rounded up): 0 * NaN must not
+    // happen, so those chunks are fetched as out-of-range zeros.
+    const bool tail_cut = (ksteps_per_tap - 1) * BK + chunk * (16 / ES) >= P.CK;
 
     // load cursor: runs one K-step ahead of the MFMAs
     int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
@@ -291,10 +296,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
     };
     auto issue_loads = [&]() {
         if (l_ks == 0) start_tap();
+        const bool cut = tail_cut && l_ks == ksteps_per_tap - 1;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             ra[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, va[i], 0, 0));
-            rb[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vb[i], 0, 0));
+            rb[i].v = __builtin_bit_cast(typename Elem<T>::vec_t,
+                                         __builtin_amdgcn_raw_buffer_load_b128(rs_in, cut ? OOB : vb[i], 0, 0));
             va[i] += BKB;  // OOB + small stays out of range
             vb[i] += BKB;
         }
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
 
     const int lr = lane / CPR, lc = lane % CPR;
     int pix_base[NG], pix_n[NG], pix_h[NG], pix_w[NG], w_base[NG], chk16[NG];
-    bool pix_ok[NG];
+    bool pix_ok[NG], tail_cut[NG];  // tail_cut: see gemm_conv_kernel
     const bool direct = !P.transposed || P.stride == 1;
     const int sgn = P.transposed ? -1 : 1;
 #pragma unroll
@@ -426,6 +433,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
 
     const int ksteps_per_tap = (P.CK + BK - 1) / BK;
     const int KT = RS * ksteps_per_tap;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) tail_cut[g] = (ksteps_per_tap - 1) * BK + chk16[g] / ES >= P.CK;
 
     int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
     int va[NG], vb[NG];
@@ -451,10 +460,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
     auto issue = [&](int buf) {
         if (l_ks == 0) start_tap();
         char* stage = smem + buf * STAGE_BYTES + wave * 32 * BKB;
+        const bool last = l_ks == ksteps_per_tap - 1;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             dma16(rs_w, stage + g * RPG * BKB, va[g]);
-            dma16(rs_in, stage + TILE_BYTES + g * RPG * BKB, vb[g]);
+            dma16(rs_in, stage + TILE_BYTES + g * RPG * BKB, (last && tail_cut[g]) ? OOB : vb[g]);
             va[g] += BKB;
             vb[g] += BKB;
         }

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os as _os
+
 import torch
 
 from . import _lib as L
@@ -65,8 +67,20 @@ def rows_of(t: torch.Tensor) -> int:
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+ROW_ALIGN_BYTES = int(_os.environ.get("BGAMD_ROW_ALIGN", "64"))   # pixel rows start on 64-byte boundaries (0: packed)
+
+
 def new_act(n, h, w, c, dtype, device) -> torch.Tensor:
-    return torch.empty((n, h, w, c), dtype=dtype, device=device)
+    """Fresh NHWC activation.  The pixel stride is rounded up to a 64-byte multiple (C = 728 bf16:
+    1456 -> 1472 bytes) so that the 64-byte K-slabs the GEMM kernels fetch per pixel, and the row
+    segments of the element-wise kernels, do not straddle memory sectors; the pad lanes are never
+    read or written (every kernel takes the pixel stride separately from C)."""
+    es = 2 if dtype == torch.bfloat16 else 4
+    q = ROW_ALIGN_BYTES // es
+    ld = (c + q - 1) // q * q if q else c
+    if ld == c:
+        return torch.empty((n, h, w, c), dtype=dtype, device=device)
+    return torch.empty((n, h, w, ld), dtype=dtype, device=device)[..., :c]
 
 
 def _f32(*shape, device):
@@ -89,8 +103,6 @@ def _e32(*shape, device):
 # that their workgroups fill the tails and ramps of the (short) kernels of the chain.  The stream is
 # joined back into the caller's stream when the autograd engine finishes the pass (queue_callback),
 # so .grad is ordered like any other result of backward().  BGAMD_NO_WGRAD_STREAM=1 disables.
-import os as _os
-
 _WG_STREAMS = {}
 _WG_PENDING = set()
 _WG_ENABLED = not _os.environ.get("BGAMD_NO_WGRAD_STREAM")
@@ -145,7 +157,7 @@ class ToInternal(torch.autograd.Function):
         n, c, h, w = x.shape
         ctx.c = c
         y = new_act(n, h, w, cp, dtype, x.device)
-        L.call("bg_nchw_to_nhwc", L.dt(dtype), x.data_ptr(), y.data_ptr(), n, c, h * w, cp, cp)
+        L.call("bg_nchw_to_nhwc", L.dt(dtype), x.data_ptr(), y.data_ptr(), n, c, h * w, cp, ld_of(y))
         return y
 
     @staticmethod
@@ -174,7 +186,7 @@ class FromInternal(torch.autograd.Function):
         g = g.contiguous().float()
         n, c, h, w = g.shape
         dx = new_act(n, h, w, ctx.cp, ctx.dtype, g.device)
-        L.call("bg_nchw_to_nhwc", L.dt(ctx.dtype), g.data_ptr(), dx.data_ptr(), n, c, h * w, ctx.cp, ctx.cp)
+        L.call("bg_nchw_to_nhwc", L.dt(ctx.dtype), g.data_ptr(), dx.data_ptr(), n, c, h * w, ctx.cp, ld_of(dx))
         return dx, None
 
 
@@ -194,7 +206,7 @@ class Conv2dFn(torch.autograd.Function):
         ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
-        desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), kp)
+        desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
         if stats is not None:
             assert bslot is None and stats.shape == (2, kp) and stats.dtype == torch.float64
             L.call("bg_conv2d_fwd_stats", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr(), stats[0].data_ptr(),
@@ -218,7 +230,7 @@ class Conv2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(n, h, w, cin, xdtype, xdev)
-            d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, cin, ld_of(g))
+            d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(dx), ld_of(g))
             L.call("bg_conv2d_bwd_data", d2, g.data_ptr(), arena.weight_t_ptr(wslot), dx.data_ptr())
         if ctx.needs_input_grad[1]:
             (x,) = ctx.saved_tensors
@@ -243,7 +255,7 @@ class DwConv3x3Fn(torch.autograd.Function):
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         ho, wo = -(-h // stride), -(-w // stride)
         y = new_act(n, ho, wo, c, x.dtype, x.device)
-        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), c)
+        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(y))
         L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
         if weight.requires_grad:
             ctx.save_for_backward(x)
@@ -258,7 +270,7 @@ class DwConv3x3Fn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(n, h, w, c, xdtype, xdev)
-            desc = L.DwDesc(L.dt(xdtype), n, h, w, c, ho, wo, stride, dil, c, ld_of(g))
+            desc = L.DwDesc(L.dt(xdtype), n, h, w, c, ho, wo, stride, dil, ld_of(dx), ld_of(g))
             L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), dx.data_ptr())
         if ctx.needs_input_grad[1]:
             (x,) = ctx.saved_tensors
@@ -306,7 +318,7 @@ class NormActFn(torch.autograd.Function):
             # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
             L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
                    momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), c, rows, c, groups, int(act))
+                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
         else:
             if kind != "identity":  # BatchNorm in eval mode: affine from the running statistics
                 mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
@@ -315,7 +327,7 @@ class NormActFn(torch.autograd.Function):
                 mean.copy_(rmean.view(1, -1))
                 rstd.copy_(torch.rsqrt(rvar + eps).view(1, -1))
             L.call("bg_norm_act_fwd", dt, x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(res),
-                   0 if res is None else ld_of(res), y.data_ptr(), c, rows, c, groups, int(act))
+                   0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.meta = (arena, gslot, bslot, kind, use_batch_stats, int(act), groups, res is not None)
         return y
@@ -337,8 +349,8 @@ class NormActFn(torch.autograd.Function):
                 return (None,) * 15
             # dx and dres are the same tensor values: write once, alias
             out = dx if dx is not None else dres
-            L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None,
-                   out.data_ptr(), c, None, 0, rows, c, groups, act)
+            L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None,
+                   out.data_ptr(), ld_of(out), None, 0, rows, c, groups, act)
             return (out if need_dx else None, out if need_res else None) + (None,) * 13
         want_affine_grads = gslot is not None and gslot.param.requires_grad
         gptr = None if gslot is None else arena.master_ptr(gslot)
@@ -348,7 +360,7 @@ class NormActFn(torch.autograd.Function):
         yptr = None if (batch_stats and not has_res) else y.data_ptr()
         if need_dx or want_affine_grads:
             s = _f64(2, groups, c, device=dev)
-            L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), yptr, c, x.data_ptr(), ld_of(x),
+            L.call("bg_norm_act_bwd_reduce", dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
                    mean.data_ptr(), rstd.data_ptr(), gptr, bptr, rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
             dg = db = None
             if want_affine_grads:
@@ -356,12 +368,13 @@ class NormActFn(torch.autograd.Function):
                 arena.ensure_grad(bslot)
                 dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
             # finalize (coefficients, dgamma/dbeta) is folded into the apply kernel
-            L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), yptr, c, x.data_ptr(), ld_of(x),
+            L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
                    s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
-                   1 if batch_stats else 0, dg, db, L.ptr(dx), c, L.ptr(dres), c, rows, c, groups, act)
+                   1 if batch_stats else 0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
+                   0 if dres is None else ld_of(dres), rows, c, groups, act)
         elif need_res:
-            L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), c, None, 0, None, None, None, None, 0,
-                   dres.data_ptr(), c, rows, c, groups, act)
+            L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
+                   0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
         return (dx, dres) + (None,) * 13
 
 
@@ -394,7 +407,7 @@ class ForkFn(torch.autograd.Function):
             n, h, w, c = acc.shape
             out = new_act(n, h, w, c, acc.dtype, acc.device)
             L.call("bg_norm_act_fwd", L.dt(acc.dtype), acc.data_ptr(), ld_of(acc), None, None, g.data_ptr(), ld_of(g),
-                   out.data_ptr(), c, n * h * w, c, 1, 0)
+                   out.data_ptr(), ld_of(out), n * h * w, c, 1, 0)
             acc = out
         return acc, None
 
@@ -413,7 +426,7 @@ class ResizeBilinearFn(torch.autograd.Function):
         n, hi, wi, c = x.shape
         out_dtype = out_dtype or x.dtype
         y = new_act(n, ho, wo, c, out_dtype, x.device)
-        L.call("bg_resize_bilinear_fwd", L.dt(x.dtype), L.dt(out_dtype), x.data_ptr(), ld_of(x), y.data_ptr(), c, n, hi,
+        L.call("bg_resize_bilinear_fwd", L.dt(x.dtype), L.dt(out_dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, hi,
                wi, ho, wo, c)
         ctx.meta = (n, hi, wi, ho, wo, c, x.dtype)
         return y
@@ -427,9 +440,9 @@ class ResizeBilinearFn(torch.autograd.Function):
             # broadcast forward -> plain column sum backward
             acc = _f32(n, c, device=g.device)
             L.call("bg_colsum", L.dt(g.dtype), g.data_ptr(), ld_of(g), n * ho * wo, c, n, 1.0, acc.data_ptr())
-            L.call("bg_cast_rows", L.F32, L.dt(in_dtype), acc.data_ptr(), c, dx.data_ptr(), c, n, c)
+            L.call("bg_cast_rows", L.F32, L.dt(in_dtype), acc.data_ptr(), c, dx.data_ptr(), ld_of(dx), n, c)
         else:
-            L.call("bg_resize_bilinear_bwd", L.dt(g.dtype), L.dt(in_dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), c, n,
+            L.call("bg_resize_bilinear_bwd", L.dt(g.dtype), L.dt(in_dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n,
                    hi, wi, ho, wo, c)
         return dx, None, None, None
 
@@ -444,7 +457,7 @@ class GlobalAvgPoolFn(torch.autograd.Function):
         acc = _f32(n, c, device=x.device)
         L.call("bg_colsum", L.dt(x.dtype), x.data_ptr(), ld_of(x), n * h * w, c, n, 1.0 / (h * w), acc.data_ptr())
         y = new_act(n, 1, 1, c, x.dtype, x.device)
-        L.call("bg_cast_rows", L.F32, L.dt(x.dtype), acc.data_ptr(), c, y.data_ptr(), c, n, c)
+        L.call("bg_cast_rows", L.F32, L.dt(x.dtype), acc.data_ptr(), c, y.data_ptr(), ld_of(y), n, c)
         ctx.meta = (n, h, w, c, x.dtype)
         return y
 
@@ -455,7 +468,7 @@ class GlobalAvgPoolFn(torch.autograd.Function):
         gf = _f32(n, c, device=g.device)
         L.call("bg_cast_rows", L.dt(g.dtype), L.F32, g.data_ptr(), c, gf.data_ptr(), c, n, c)
         dx = new_act(n, h, w, c, dtype, g.device)
-        L.call("bg_broadcast_rows", L.dt(dtype), gf.data_ptr(), 1.0 / (h * w), dx.data_ptr(), c, n * h * w, c, n)
+        L.call("bg_broadcast_rows", L.dt(dtype), gf.data_ptr(), 1.0 / (h * w), dx.data_ptr(), ld_of(dx), n * h * w, c, n)
         return dx
 
 
@@ -471,7 +484,7 @@ class ConcatFn(torch.autograd.Function):
         off = 0
         dt = L.dt(out.dtype)
         for x, c in zip(xs, cs):
-            L.call("bg_cast_rows", dt, dt, x.data_ptr(), ld_of(x), out.data_ptr() + off * out.element_size(), sum(cs),
+            L.call("bg_cast_rows", dt, dt, x.data_ptr(), ld_of(x), out.data_ptr() + off * out.element_size(), ld_of(out),
                    n * h * w, c)
             off += c
         ctx.cs = cs
@@ -519,7 +532,7 @@ class LinearHeadFn(torch.autograd.Function):
             arena.ensure_grad(bslot)
             dw, db = arena.grad_ptr(wslot), arena.grad_ptr(bslot)
         L.call("bg_linear_head_bwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), arena.master_ptr(wslot), g.data_ptr(), L.ptr(dx),
-               c, dw, db, n, h * w, c)
+               0 if dx is None else ld_of(dx), dw, db, n, h * w, c)
         return dx, None, None, None, None, None
 
 
