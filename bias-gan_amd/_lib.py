@@ -69,6 +69,7 @@ _SIGS = {
                              c_vp],
     "bg_norm_act_bwd_apply": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
                               c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_avgpool2x2": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_resize_bilinear_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_resize_bilinear_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_colsum": [c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp],

@@ -89,6 +89,31 @@ class Conv2d(BGModule):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size[0]}, s={self.stride[0]}, groups={self.groups}"
 
 
+class ConvTranspose2d(BGModule):
+    """nn.ConvTranspose2d(groups=1, bias=False) parameter container (weight [Cin, Cout, k, k]).  The
+    arena stores it as the dense convolution it is the adjoint of ([K = Cin, C = Cout])."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=(0, 0), bias=False):
+        super().__init__()
+        assert not bias, "the transposed convolutions on this path have no bias"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (kernel_size, kernel_size)
+        self.stride, self.padding = (stride,) * 2, (padding,) * 2
+        self.output_padding = tuple(output_padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, kernel_size, kernel_size))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self.bias = None
+        self._bg_param_layout = {"weight": _conv_layout}
+
+    def forward(self, x):
+        a = self.arena()
+        return ops.ConvTranspose2dFn.apply(x, self.weight, a, a.by_param[id(self.weight)], self.stride[0], self.padding[0],
+                                           self.output_padding)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size[0]}, s={self.stride[0]}, op={self.output_padding}"
+
+
 def _norm_kind(m: nn.Module) -> str:
     if isinstance(m, nn.BatchNorm2d):
         if not (m.affine and m.track_running_stats):
@@ -356,6 +381,95 @@ class InterpolationUpsampler(BGModule):
         return ops.ResizeBilinearFn.apply(x, H, W, torch.float32)
 
 
+def _norm_pool_act(owner: BGModule, m: nn.Module, pool: nn.Module, x):
+    """normalizer -> nnpooler -> LeakyReLU(0.2), the tail of every Deconv unit (deeplab.py:406-409)."""
+    if isinstance(pool, nn.AvgPool2d):
+        p = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+        return ops.leaky_relu(ops.avgpool2x2(apply_norm(owner, m, x, act=False), p))
+    return apply_norm(owner, m, x, act=True)  # nn_pooling=False: nn.Identity in its place
+
+
+def _deconv_init(mod: nn.Module):
+    # DeconvUpsampler/UpsamplerExtension.__init_weight (deeplab.py:446-462,500-516): the same normal
+    # fill for Conv2d and ConvTranspose2d, n = k*k*out_channels
+    gain = nn.init.calculate_gain("leaky_relu", 0.2)
+    for m in mod.modules():
+        if isinstance(m, (Conv2d, ConvTranspose2d)):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            nn.init.normal_(m.weight, mean=0.0, std=gain / math.sqrt(n))
+
+
+class DeconvUpsampler(BGModule):
+    """Four stride-2 transposed convolutions with hand-tuned output paddings, each followed by
+    normaliser -> AvgPool2d(2, 1) (anti-checkerboard) -> LeakyReLU, around the skip concat and the
+    3x3 / 3x3 / 1x1 stack (deeplab.py:398-444).  Shape-locked by those paddings to H = 16a-13,
+    W = 16b-11 inputs (19x37: the 10-degree GPS-RO grid); other sizes fail at the concat like the
+    reference does."""
+
+    def __init__(self, n_output, normalizer=nn.BatchNorm2d, nn_pooling=True):
+        super().__init__()
+        pooler = nn.AvgPool2d if nn_pooling else (lambda *a, **k: nn.Identity())
+
+        def unit(cin, cout, pad, op):
+            return nn.Sequential(ConvTranspose2d(cin, cout, 3, stride=2, padding=pad, output_padding=op, bias=False),
+                                 normalizer(cout), pooler(2, stride=1, padding=0), nn.LeakyReLU(0.2, inplace=True))
+        self.deconv1 = unit(256, 256, 1, (0, 1))
+        self.deconv2 = unit(256, 256, 0, (1, 0))
+        self.conv1 = nn.Sequential(Conv2d(304, 256, 3, stride=1, padding=1, bias=False), normalizer(256),
+                                   nn.LeakyReLU(0.2, inplace=True),
+                                   Conv2d(256, 256, 3, stride=1, padding=1, bias=False), normalizer(256),
+                                   nn.LeakyReLU(0.2, inplace=True), Conv2d(256, 256, 1, stride=1))
+        self.deconv3 = unit(256, 128, 1, (1, 0))
+        self.last_deconv = nn.Sequential(ConvTranspose2d(128, n_output, 3, stride=2, padding=1, output_padding=(1, 1),
+                                                         bias=False))
+        _deconv_init(self)
+
+    def _unit(self, seq, x):
+        return _norm_pool_act(self, seq[1], seq[2], seq[0](x))
+
+    def forward(self, x, low_level_features, input_size):
+        x = self._unit(self.deconv1, x)
+        x = self._unit(self.deconv2, x)
+        if tuple(x.shape[1:3]) != tuple(low_level_features.shape[1:3]):
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: the Deconv upsampler needs "
+                               "H = 16a-13, W = 16b-11 (got a {}x{} decoder map for a {}x{} skip)".format(
+                                   x.shape[1], x.shape[2], low_level_features.shape[1], low_level_features.shape[2]))
+        x = ops.concat(x, low_level_features)
+        c1 = self.conv1
+        x = conv_norm(self, c1[0], c1[1], x, act=True)
+        x = conv_norm(self, c1[3], c1[4], x, act=True)
+        x = c1[6](x)
+        x = self._unit(self.deconv3, x)
+        return self.last_deconv[0](x)
+
+
+class UpsamplerExtension(BGModule):
+    """Full-resolution stem on the raw input + normalised decoder output -> 3x3 / 3x3 to n_output
+    (deeplab.py:465-498)."""
+
+    def __init__(self, n_input, n_output, normalizer=nn.BatchNorm2d, nn_pooling=True):
+        super().__init__()
+        pooler = nn.AvgPool2d if nn_pooling else (lambda *a, **k: nn.Identity())
+        self.init_norm = nn.Sequential(normalizer(128), pooler(2, stride=1, padding=1), nn.LeakyReLU(0.2, inplace=True))
+        self.conv1 = nn.Sequential(Conv2d(n_input, 64, 3, stride=1, padding=1, bias=False), normalizer(64),
+                                   nn.LeakyReLU(0.2, inplace=True),
+                                   Conv2d(64, 128, 3, stride=1, padding=1, bias=False), normalizer(128),
+                                   nn.LeakyReLU(0.2, inplace=True))
+        self.conv2 = nn.Sequential(Conv2d(256, 64, 3, stride=1, padding=1, bias=False), normalizer(64),
+                                   nn.LeakyReLU(0.2, inplace=True),
+                                   Conv2d(64, n_output, 3, stride=1, padding=1, bias=False))
+        _deconv_init(self)
+
+    def forward(self, input, x):
+        c1, c2 = self.conv1, self.conv2
+        skip = conv_norm(self, c1[0], c1[1], input, act=True)
+        skip = conv_norm(self, c1[3], c1[4], skip, act=True)
+        x = _norm_pool_act(self, self.init_norm[0], self.init_norm[1], x)
+        x = ops.concat(x, skip)
+        x = conv_norm(self, c2[0], c2[1], x, act=True)
+        return c2[3](x)
+
+
 class DeepLabv3_plus(BGModule):
     """Encoder-ASPP-decoder (deeplab.py:585-684)."""
 
@@ -390,13 +504,18 @@ class DeepLabv3_plus(BGModule):
         if self.upsampler_type == "Interpolate":
             self.upsample = InterpolationUpsampler(n_output, normalizer)
         elif self.upsampler_type.startswith("Deconv"):
-            raise NotImplementedError(
-                "The Deconv/Deconv1x upsamplers (ConvTranspose2d chain, deeplab.py:398-500) are shape-locked to "
-                "H=16a-13, W=16b-11 grids and are not built on the HIP path yet; use upsampler_type='Interpolate'.")
+            self.upsample = DeconvUpsampler(n_output=128 if self.upsampler_type == "Deconv1x" else n_output,
+                                            normalizer=normalizer, nn_pooling=nn_pooling)
         else:
             raise NotImplementedError("Error, upsampler {} not implemented.".format(upsampler_type))
+        if self.upsampler_type in ("Deconv1x", "Interpolate1x"):
+            self.upsample_extension = UpsamplerExtension(n_input, n_output, normalizer, nn_pooling)
+        elif self.upsampler_type == "Deconv":
+            self.final_pool = nn.AvgPool2d(2, stride=1, padding=1) if nn_pooling else nn.Identity()
 
     def forward_nhwc(self, xi, H, W):
+        if self.upsampler_type == "Deconv1x":
+            xi, x_raw = ops.fork(xi, 2)              # the extension reads the raw input again
         x, low = self.xception_features.forward_nhwc(xi)
         x1i, x2i, x3i, x4i, x5i = ops.fork(x, 5)
         x1, x2, x3, x4 = self.aspp1(x1i), self.aspp2(x2i), self.aspp3(x3i), self.aspp4(x4i)
@@ -406,7 +525,12 @@ class DeepLabv3_plus(BGModule):
         x = ops.concat(x1, x2, x3, x4, x5)
         x = conv_norm(self, self.conv1, self.bn1, x, act=True)
         low = conv_norm(self, self.conv2, self.bn2, low, act=True)
-        return self.upsample(x, low, (H, W))
+        x = self.upsample(x, low, (H, W))
+        if self.upsampler_type == "Deconv1x":        # deeplab.py:679-682
+            x = self.upsample_extension(x_raw, x)
+        elif self.upsampler_type == "Deconv" and isinstance(self.final_pool, nn.AvgPool2d):
+            x = ops.avgpool2x2(x, 1)
+        return x
 
     def forward(self, input):
         """NCHW fp32 [N, n_input, H, W] -> NCHW fp32 [N, n_output, H, W]."""

@@ -239,6 +239,41 @@ __global__ void nhwc_to_nchw_kernel(const T* src, int lds, float* dst, int N, in
     }
 }
 
+// AvgPool2d(kernel 2, stride 1, count_include_pad): y[n,h,w,:] = 0.25 * sum_{i,j in {0,1}}
+// x[n, h+off+i, w+off+j, :], zero outside the input.  off = -padding is the forward pass,
+// off = padding-1 with the roles of x and y exchanged is its adjoint.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2x2_kernel(const T* x, int ldx, T* y, int ldy, int Hi, int Wi, int Ho, int Wo, int C,
+                                                         int off) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // (wo, channel vector) of one output row
+    if (idx >= Wo * cv) return;
+    const int wo = idx / cv, c = (idx - wo * cv) * VEC;
+    const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ih = ho + off + i;
+        if ((unsigned)ih >= (unsigned)Hi) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iw = wo + off + j;
+            if ((unsigned)iw >= (unsigned)Wi) continue;
+            Chunk<T> v;
+            v.load(x + (((long long)n * Hi + ih) * Wi + iw) * ldx + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += v.get(e);
+        }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, 0.25f * acc[e]);
+    o.store(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + c);
+}
+
 __global__ void fill_kernel(float* p, float v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         p[i] = v;
@@ -366,6 +401,20 @@ extern "C" int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, 
     BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(ew_grid(total)), dim3(256), 0,
                                                        (hipStream_t)stream, (const T*)src, lds, dst, N, C, HW));
     BG_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_avgpool2x2(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Hi,
+                             int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, int32_t off, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bg_avgpool2x2: bad args");
+    const int vec = dtype_vec(dtype);
+    BG_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0 && ldx >= C && ldy >= C && aligned16(x) && aligned16(y),
+                 "bg_avgpool2x2: C/ld must be multiples of %d and pointers 16-byte aligned", vec);
+    BG_CHECK_ARG((long long)N * Ho <= 65535, "bg_avgpool2x2: N*Ho too large for this launch shape");
+    const int items = Wo * (C / vec);
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((avgpool2x2_kernel<T>), dim3((items + 255) / 256, N * Ho), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, Hi, Wi, Ho, Wo, C, off));
+    BG_CHECK_LAUNCH("avgpool2x2_kernel");
     return BG_OK;
 }
 

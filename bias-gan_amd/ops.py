@@ -245,6 +245,77 @@ class Conv2dFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None, None, None
 
 
+class ConvTranspose2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(groups=1, bias=False) of the Deconv upsamplers (deeplab.py:406-431).
+
+    A transposed convolution IS the data gradient of the convolution with the same weight tensor
+    ([Cin_t, Cout_t, k, k] = that convolution's [Cout, Cin, k, k]), so the three GEMM entry points
+    are used with their roles exchanged: forward = bg_conv2d_bwd_data, input gradient =
+    bg_conv2d_fwd, weight gradient = bg_conv2d_bwd_weight(x := dy, dy := x)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, stride, pad, out_pad):
+        x = nhwc(x)
+        n, h, w, cin = x.shape
+        kp, kh, kw, cp = wslot.phys_shape            # K = Cin_t (padded), C = Cout_t (padded)
+        assert cin == kp, f"transposed conv expects {kp} input channels (padded), got {cin}"
+        ho = (h - 1) * stride - 2 * pad + kh + out_pad[0]
+        wo = (w - 1) * stride - 2 * pad + kw + out_pad[1]
+        assert (ho + 2 * pad - kh) // stride + 1 == h and (wo + 2 * pad - kw) // stride + 1 == w, "bad output_padding"
+        y = new_act(n, ho, wo, cp, x.dtype, x.device)
+        desc = L.ConvDesc(L.dt(x.dtype), n, ho, wo, cp, h, w, kp, kh, kw, stride, pad, 1, ld_of(y), ld_of(x))
+        L.call("bg_conv2d_bwd_data", desc, x.data_ptr(), arena.weight_t_ptr(wslot), y.data_ptr())
+        if weight.requires_grad:
+            ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, stride, pad, ho, wo, tuple(x.shape), x.dtype, x.device)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        arena, wslot, stride, pad, ho, wo, xshape, xdtype, xdev = ctx.meta
+        g = nhwc(g)
+        n, h, w, cin = xshape
+        kp, kh, kw, cp = wslot.phys_shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(n, h, w, kp, xdtype, xdev)
+            desc = L.ConvDesc(L.dt(xdtype), n, ho, wo, cp, h, w, kp, kh, kw, stride, pad, 1, ld_of(g), ld_of(dx))
+            L.call("bg_conv2d_fwd", desc, g.data_ptr(), arena.weight_ptr(wslot), None, dx.data_ptr())
+        if ctx.needs_input_grad[1]:
+            (x,) = ctx.saved_tensors
+            arena.ensure_grad(wslot)
+            desc = L.ConvDesc(L.dt(xdtype), n, ho, wo, cp, h, w, kp, kh, kw, stride, pad, 1, ld_of(g), ld_of(x))
+            with _WgradStream(xdev, x, g):
+                L.call("bg_conv2d_bwd_weight", desc, g.data_ptr(), x.data_ptr(), arena.grad_ptr(wslot), None)
+        return dx, None, None, None, None, None, None
+
+
+class AvgPool2x2Fn(torch.autograd.Function):
+    """nn.AvgPool2d(2, stride=1, padding=p), p in {0, 1} (deeplab.py:402,469,649)."""
+
+    @staticmethod
+    def forward(ctx, x, p: int):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        ho, wo = h + 2 * p - 1, w + 2 * p - 1
+        y = new_act(n, ho, wo, c, x.dtype, x.device)
+        L.call("bg_avgpool2x2", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, h, w, ho, wo, c, -p)
+        ctx.meta = (n, h, w, ho, wo, c, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, ho, wo, c, p = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n, h, w, c, g.dtype, g.device)
+        L.call("bg_avgpool2x2", L.dt(g.dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, ho, wo, h, w, c, p - 1)
+        return dx, None
+
+
+def avgpool2x2(x, p: int):
+    return AvgPool2x2Fn.apply(x, int(p))
+
+
 class DwConv3x3Fn(torch.autograd.Function):
     """Depthwise 3x3 of SeparableConv2d_same with fixed_padding folded in (bg_dwconv3x3_*)."""
 

@@ -199,6 +199,12 @@ int bg_nchw_to_nhwc(int32_t dst_dtype, const float* src, void* dst, int32_t N, i
 int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, float* dst, int32_t N, int32_t C, int32_t HW,
                     void* stream);
 int bg_fill_f32(float* p, float v, int64_t n, void* stream);
+/* nn.AvgPool2d(2, stride=1, padding=p) of the Deconv upsamplers (deeplab.py:402-429,469-471,
+ * 649-651; count_include_pad): y[n,h,w,:] = 0.25 * sum_{i,j in {0,1}} x[n,h+off+i,w+off+j,:], zero
+ * outside x.  Forward: off = -p, Ho = Hi+2p-1.  Backward: the same call with x := dy, y := dx,
+ * off = p-1 and the sizes exchanged. */
+int bg_avgpool2x2(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Hi, int32_t Wi,
+                  int32_t Ho, int32_t Wo, int32_t C, int32_t off, void* stream);
 int bg_axpy_rows(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int64_t rows, int32_t C,
                  void* stream); /* y += x */
 

@@ -144,8 +144,9 @@ def xception_spec(prefix: str, cin: int, norm: str, os: int = 16) -> List[Tuple[
     return s
 
 
-def deeplab_spec(prefix: str, cin: int, cout: int, norm: str, os: int = 16):
-    """DeepLabv3_plus with the Interpolate upsampler (deeplab.py:604-635,363-369)."""
+def deeplab_spec(prefix: str, cin: int, cout: int, norm: str, os: int = 16, upsampler: str = "Interpolate"):
+    """DeepLabv3_plus (deeplab.py:604-651) with the Interpolate (:363-369), Deconv or Deconv1x
+    (:398-431, :465-487) upsampler; entries in the reference's state_dict order."""
     s = xception_spec(prefix + "xception_features.", cin, norm, os)
     for i in (1, 2, 3, 4):
         k = 1 if i == 1 else 3
@@ -157,20 +158,49 @@ def deeplab_spec(prefix: str, cin: int, cout: int, norm: str, os: int = 16):
     s += _norm_entries(prefix + "bn1", 256, norm)
     s.append((prefix + "conv2.weight", (48, 128, 1, 1), "conv"))
     s += _norm_entries(prefix + "bn2", 48, norm)
-    up = prefix + "upsample.last_conv."
-    s.append((up + "0.weight", (256, 304, 3, 3), "conv"))
-    s += _norm_entries(up + "1", 256, norm)
-    s.append((up + "3.weight", (256, 256, 3, 3), "conv"))
-    s += _norm_entries(up + "4", 256, norm)
-    s.append((up + "6.weight", (cout, 256, 1, 1), "conv"))
-    s.append((up + "6.bias", (cout,), "bias"))
+    if upsampler == "Interpolate":
+        up = prefix + "upsample.last_conv."
+        s.append((up + "0.weight", (256, 304, 3, 3), "conv"))
+        s += _norm_entries(up + "1", 256, norm)
+        s.append((up + "3.weight", (256, 256, 3, 3), "conv"))
+        s += _norm_entries(up + "4", 256, norm)
+        s.append((up + "6.weight", (cout, 256, 1, 1), "conv"))
+        s.append((up + "6.bias", (cout,), "bias"))
+        return s
+    assert upsampler in ("Deconv", "Deconv1x"), upsampler
+    n_up = 128 if upsampler == "Deconv1x" else cout
+    up = prefix + "upsample."
+    # nn.ConvTranspose2d weights are [Cin, Cout, k, k]
+    s.append((up + "deconv1.0.weight", (256, 256, 3, 3), "conv"))
+    s += _norm_entries(up + "deconv1.1", 256, norm)
+    s.append((up + "deconv2.0.weight", (256, 256, 3, 3), "conv"))
+    s += _norm_entries(up + "deconv2.1", 256, norm)
+    s.append((up + "conv1.0.weight", (256, 304, 3, 3), "conv"))
+    s += _norm_entries(up + "conv1.1", 256, norm)
+    s.append((up + "conv1.3.weight", (256, 256, 3, 3), "conv"))
+    s += _norm_entries(up + "conv1.4", 256, norm)
+    s.append((up + "conv1.6.weight", (256, 256, 1, 1), "conv"))
+    s.append((up + "conv1.6.bias", (256,), "bias"))
+    s.append((up + "deconv3.0.weight", (256, 128, 3, 3), "conv"))
+    s += _norm_entries(up + "deconv3.1", 128, norm)
+    s.append((up + "last_deconv.0.weight", (128, n_up, 3, 3), "conv"))
+    if upsampler == "Deconv1x":
+        ex = prefix + "upsample_extension."
+        s += _norm_entries(ex + "init_norm.0", 128, norm)
+        s.append((ex + "conv1.0.weight", (64, cin, 3, 3), "conv"))
+        s += _norm_entries(ex + "conv1.1", 64, norm)
+        s.append((ex + "conv1.3.weight", (128, 64, 3, 3), "conv"))
+        s += _norm_entries(ex + "conv1.4", 128, norm)
+        s.append((ex + "conv2.0.weight", (64, 256, 3, 3), "conv"))
+        s += _norm_entries(ex + "conv2.1", 64, norm)
+        s.append((ex + "conv2.3.weight", (cout, 64, 3, 3), "conv"))
     return s
 
 
-def generator_spec(cin: int, cout: int, noise_dims: int, norm: str, os: int = 16):
+def generator_spec(cin: int, cout: int, noise_dims: int, norm: str, os: int = 16, upsampler: str = "Interpolate"):
     """Generator = noise concat + DeepLabv3_plus under key prefix 'model.'
     (deeplab_gan.py:64-94)."""
-    return deeplab_spec("model.", cin + noise_dims, cout, norm, os)
+    return deeplab_spec("model.", cin + noise_dims, cout, norm, os, upsampler)
 
 
 def discriminator_spec(cin: int, h: int, w: int, norm: str, os: int = 16):
@@ -357,8 +387,45 @@ def bilinear_ac(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
     return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
 
+def _deconv_unit(P: State, key: str, x: torch.Tensor, ctx: NormCtx, pad: int, out_pad, pool: bool = True):
+    """ConvTranspose2d(3, stride 2, no bias) -> normaliser -> AvgPool2d(2, 1, 0) -> LeakyReLU
+    (one nn.Sequential of DeconvUpsampler, deeplab.py:406-430)."""
+    q = ctx.q
+    x = q(F.conv_transpose2d(x, q(P[key + ".0.weight"]), None, 2, pad, out_pad))
+    x = q(norm(P, key + ".1", x, ctx))
+    if pool:
+        x = q(F.avg_pool2d(x, 2, 1, 0))
+    return q(lrelu(x))
+
+
+def deconv_upsampler(P: State, up: str, x: torch.Tensor, low: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
+    """DeconvUpsampler.forward (deeplab.py:436-444)."""
+    q = ctx.q
+    x = _deconv_unit(P, up + "deconv1", x, ctx, 1, (0, 1))
+    x = _deconv_unit(P, up + "deconv2", x, ctx, 0, (1, 0))
+    x = torch.cat((x, low), dim=1)
+    x = q(lrelu(norm(P, up + "conv1.1", q(F.conv2d(x, q(P[up + "conv1.0.weight"]), None, 1, 1)), ctx)))
+    x = q(lrelu(norm(P, up + "conv1.4", q(F.conv2d(x, q(P[up + "conv1.3.weight"]), None, 1, 1)), ctx)))
+    x = q(F.conv2d(x, q(P[up + "conv1.6.weight"]), P[up + "conv1.6.bias"]))
+    x = _deconv_unit(P, up + "deconv3", x, ctx, 1, (1, 0))
+    return q(F.conv_transpose2d(x, q(P[up + "last_deconv.0.weight"]), None, 2, 1, (1, 1)))
+
+
+def upsampler_extension(P: State, ex: str, x_in: torch.Tensor, x: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
+    """UpsamplerExtension.forward (deeplab.py:489-498)."""
+    q = ctx.q
+    skip = q(lrelu(norm(P, ex + "conv1.1", q(F.conv2d(x_in, q(P[ex + "conv1.0.weight"]), None, 1, 1)), ctx)))
+    skip = q(lrelu(norm(P, ex + "conv1.4", q(F.conv2d(skip, q(P[ex + "conv1.3.weight"]), None, 1, 1)), ctx)))
+    x = q(norm(P, ex + "init_norm.0", x, ctx))
+    x = q(lrelu(q(F.avg_pool2d(x, 2, 1, 1))))
+    x = torch.cat((x, skip), dim=1)
+    x = q(lrelu(norm(P, ex + "conv2.1", q(F.conv2d(x, q(P[ex + "conv2.0.weight"]), None, 1, 1)), ctx)))
+    return q(F.conv2d(x, q(P[ex + "conv2.3.weight"]), None, 1, 1))
+
+
 def deeplab(P: State, prefix: str, x_in: torch.Tensor, ctx: NormCtx, os: int = 16) -> torch.Tensor:
-    """DeepLabv3_plus.forward with the Interpolate upsampler (deeplab.py:654-684,374-381)."""
+    """DeepLabv3_plus.forward (deeplab.py:654-684); the upsampler in use is read off the state's keys:
+    Interpolate (:374-381), Deconv (+ final AvgPool2d(2,1,1), :681-682) or Deconv1x (+ extension)."""
     q = ctx.q
     rates = [1, 6, 12, 18] if os == 16 else [1, 12, 24, 36]
     x, low = xception(P, prefix + "xception_features.", x_in, ctx, os)
@@ -375,6 +442,11 @@ def deeplab(P: State, prefix: str, x_in: torch.Tensor, ctx: NormCtx, os: int = 1
     x = q(lrelu(norm(P, prefix + "bn1", q(F.conv2d(x, q(P[prefix + "conv1.weight"]))), ctx)))
     low = q(lrelu(norm(P, prefix + "bn2", q(F.conv2d(low, q(P[prefix + "conv2.weight"]))), ctx)))
     H, W = x_in.shape[2], x_in.shape[3]
+    if prefix + "upsample.deconv1.0.weight" in P:
+        x = deconv_upsampler(P, prefix + "upsample.", x, low, ctx)
+        if prefix + "upsample_extension.conv1.0.weight" in P:
+            return upsampler_extension(P, prefix + "upsample_extension.", x_in, x, ctx)
+        return q(F.avg_pool2d(x, 2, 1, 1))
     x = q(bilinear_ac(x, (ceil_div(H, 4), ceil_div(W, 4))))
     x = torch.cat((x, low), dim=1)
     up = prefix + "upsample.last_conv."

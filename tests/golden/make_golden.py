@@ -38,10 +38,10 @@ from oracle import gan_oracle as orc  # noqa: E402  (only for specs / determinis
 torch.set_num_threads(8)
 
 
-def build_ref_generator(c, norm_cls, seed):
-    g = ref_gan.Generator(c, c, "Interpolate", "Uniform", 0, os=16, pretrained=False, normalizer=norm_cls)
+def build_ref_generator(c, norm_cls, seed, upsampler="Interpolate"):
+    g = ref_gan.Generator(c, c, upsampler, "Uniform", 0, os=16, pretrained=False, normalizer=norm_cls)
     kind = "batch" if norm_cls is nn.BatchNorm2d else "instance"
-    spec = orc.generator_spec(c, c, 0, kind)
+    spec = orc.generator_spec(c, c, 0, kind, upsampler=upsampler)
     sd = g.state_dict()
     assert [k for k, _, _ in spec] == list(sd.keys()), "generator key order differs from the reference"
     for k, shape, _ in spec:
@@ -80,8 +80,8 @@ GRAD_FULL_D = ["xception_features.bn1.weight", "xception_features.block1.skipbn.
                "xception_features.block7.rep.4.conv1.weight", "xception_features.bn5.weight"]
 
 
-def golden_generator(tag, c, h, w, n, seed):
-    g, spec = build_ref_generator(c, nn.BatchNorm2d, seed)
+def golden_generator(tag, c, h, w, n, seed, upsampler="Interpolate", grad_full=None, bufs=None):
+    g, spec = build_ref_generator(c, nn.BatchNorm2d, seed, upsampler)
     g.train()
     x, y = orc.synthetic_fields(n, c, h, w, seed + 100)
     out = g(x)
@@ -92,18 +92,18 @@ def golden_generator(tag, c, h, w, n, seed):
     res["grad_keys"] = np.array(list(cs.keys()))
     res["grad_cs"] = np.stack(list(cs.values()))
     named = dict(g.named_parameters())
-    for k in GRAD_FULL_G:
+    for k in (grad_full or GRAD_FULL_G):
         res["grad::" + k] = named[k].grad.numpy()
     sd = g.state_dict()
-    for k in ("model.xception_features.bn1.running_mean", "model.xception_features.bn1.running_var",
-              "model.global_avg_pool.2.running_var", "model.upsample.last_conv.4.running_mean"):
+    for k in (bufs or ("model.xception_features.bn1.running_mean", "model.xception_features.bn1.running_var",
+                       "model.global_avg_pool.2.running_var", "model.upsample.last_conv.4.running_mean")):
         res["buf::" + k] = sd[k].numpy()
     # eval-mode forward with the now-updated running stats
     g.eval()
     with torch.no_grad():
         res["out_eval"] = g(x).numpy()
     np.savez_compressed(os.path.join(HERE, f"generator_{tag}.npz"), meta=json.dumps(
-        dict(c=c, h=h, w=w, n=n, seed=seed, field_seed=seed + 100)), **res)
+        dict(c=c, h=h, w=w, n=n, seed=seed, field_seed=seed + 100, upsampler=upsampler)), **res)
     print("generator", tag, "loss", loss.item())
 
 
@@ -366,6 +366,19 @@ if __name__ == "__main__":
     if "all" in which or "gen" in which:
         golden_generator("c4_64x64", 4, 64, 64, 2, seed=1)
         golden_generator("c8_40x56", 8, 40, 56, 2, seed=2)
+    if "all" in which or "deconv" in which:
+        # the Deconv upsamplers only exist on H = 16a-13, W = 16b-11 grids (19x37 is the GPS-RO grid)
+        golden_generator("deconv_c4_19x37", 4, 19, 37, 2, seed=6, upsampler="Deconv",
+                         grad_full=["model.upsample.deconv1.1.bias", "model.upsample.deconv2.1.weight",
+                                    "model.upsample.conv1.6.bias", "model.upsample.deconv3.1.weight",
+                                    "model.upsample.last_deconv.0.weight", "model.xception_features.bn1.weight"],
+                         bufs=["model.upsample.deconv1.1.running_mean", "model.upsample.deconv3.1.running_var"])
+        golden_generator("deconv1x_c4_19x37", 4, 19, 37, 2, seed=7, upsampler="Deconv1x",
+                         grad_full=["model.upsample.last_deconv.0.weight", "model.upsample_extension.conv1.0.weight",
+                                    "model.upsample_extension.init_norm.0.weight",
+                                    "model.upsample_extension.conv2.3.weight", "model.upsample.deconv2.1.bias"],
+                         bufs=["model.upsample_extension.init_norm.0.running_mean",
+                               "model.upsample_extension.conv2.1.running_var"])
     if "all" in which or "disc" in which:
         golden_discriminator("c4_64x64_bn", 4, 64, 64, 2, 3, nn.BatchNorm2d)
         golden_discriminator("c8_40x56_bn", 8, 40, 56, 3, 4, nn.BatchNorm2d)

@@ -32,6 +32,20 @@ def test_state_dict_keys_match_reference(golden_dir, capsys):
     assert all("running" not in k for k in Di.state_dict())
 
 
+@pytest.mark.parametrize("upsampler", ["Deconv", "Deconv1x"])
+def test_deconv_state_dict_keys_match_reference(upsampler):
+    """Key order and shapes of the Deconv variants: the oracle's spec was asserted equal to the reference's
+    state_dict when the goldens were generated (tests/golden/make_golden.py: build_ref_generator)."""
+    from oracle import gan_oracle as orc
+    G = dxg.Generator(4, 4, upsampler, "Uniform", 0, normalizer=nn.BatchNorm2d)
+    spec = orc.generator_spec(4, 4, 0, "batch", upsampler=upsampler)
+    assert [(k, tuple(v.shape)) for k, v in G.state_dict().items()] == [(k, tuple(sh)) for k, sh, _ in spec]
+    # nn_pooling=False swaps the AvgPool2d for nn.Identity without shifting any key
+    from bias_gan_amd.architecture.gpsro import deeplab as dl
+    Gn = dl.DeepLabv3_plus(4, 4, 16, upsampler, False, False, nn.BatchNorm2d, nn_pooling=False)
+    assert ["model." + k for k in Gn.state_dict()] == [k for k, _, _ in spec]
+
+
 def test_init_distributions_follow_reference():
     torch.manual_seed(0)
     D = dxg.Discriminator(16, normalizer=nn.BatchNorm2d, input_size=(64, 64))

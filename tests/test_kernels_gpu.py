@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 import bias_gan_amd  # noqa: E402
 from bias_gan_amd import _lib as L  # noqa: E402
+from bias_gan_amd import ops  # noqa: E402
 
 DEV = "cuda"
 DTYPES = [torch.float32, torch.bfloat16]
@@ -566,3 +567,50 @@ def test_norm_act_bwd_sign_recomputed_from_x(dtype, mode):
     if aff:
         assert_close(out[False][1], out[True][1], 1e-6, "dgamma")
         assert_close(out[False][2], out[True][2], 1e-6, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("p", [0, 1])
+def test_avgpool2x2(dtype, p):
+    """bg_avgpool2x2 forward and adjoint vs F.avg_pool2d(2, 1, p) (count_include_pad default)."""
+    n, c, h, w = 2, 24, 7, 10
+    x = rnd((n, c, h, w), 51, dtype).requires_grad_(True)
+    ref = F.avg_pool2d(x, 2, 1, p)
+    go = rnd(tuple(ref.shape), 52, dtype)
+    ref.backward(go)
+    ho, wo = h + 2 * p - 1, w + 2 * p - 1
+    (xb, xv), (gb, gv) = to_nhwc(x.detach(), dtype), to_nhwc(go, dtype)
+    cp = xv.shape[-1]
+    y = torch.zeros(n, ho, wo, cp, dtype=dtype, device=DEV)
+    L.call("bg_avgpool2x2", L.dt(dtype), xv.data_ptr(), cp, y.data_ptr(), cp, n, h, w, ho, wo, cp, -p)
+    assert_close(from_nhwc(y, c), ref.detach(), tol(dtype), "y")
+    dx = torch.zeros(n, h, w, cp, dtype=dtype, device=DEV)
+    L.call("bg_avgpool2x2", L.dt(dtype), gv.data_ptr(), cp, dx.data_ptr(), cp, n, ho, wo, h, w, cp, p - 1)
+    assert_close(from_nhwc(dx, c), x.grad, tol(dtype), "dx")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("pad,op", [(1, (0, 1)), (0, (1, 0)), (1, (1, 0)), (1, (1, 1))])
+def test_conv_transpose_via_conv_entry_points(dtype, pad, op):
+    """nn.ConvTranspose2d(3, stride 2, output_padding as in deeplab.py:406-431) through ops.ConvTranspose2dFn:
+    forward = bg_conv2d_bwd_data, input gradient = bg_conv2d_fwd, weight gradient = bg_conv2d_bwd_weight."""
+    from bias_gan_amd.architecture.gpsro import deeplab as dl
+    n, cin, cout, h, w = 2, 24, 16, 5, 6
+    m = dl.ConvTranspose2d(cin, cout, 3, stride=2, padding=pad, output_padding=op).set_compute_dtype(dtype)
+    wt = rnd((cin, cout, 3, 3), 61, dtype, 0.2)
+    m.weight.data.copy_(wt)
+    m.to(DEV)
+    x = rnd((n, cin, h, w), 62, dtype)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, None, 2, pad, op)
+    go = rnd(tuple(ref.shape), 63, dtype)
+    ref.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    xi = ops.ToInternal.apply(xd, up(cin, dtype), dtype)
+    y = ops.FromInternal.apply(m(xi), cout)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert_close(y.detach().cpu(), ref.detach(), tol(dtype), "y")
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    assert_close(xd.grad.cpu(), xr.grad, tol(dtype) * 2, "dx")
+    assert_close(m.weight.grad.cpu(), wr.grad, 5e-4 if dtype == torch.float32 else 2e-2, "dw")

@@ -59,11 +59,11 @@ def test_block(golden_dir, tag):
     _close(expect.numpy(), z[tag + "::x_after"], what="input aliasing")
 
 
-@pytest.mark.parametrize("tag", ["c4_64x64", "c8_40x56"])
+@pytest.mark.parametrize("tag", ["c4_64x64", "c8_40x56", "deconv_c4_19x37", "deconv1x_c4_19x37"])
 def test_generator(golden_dir, tag):
     z = np.load(os.path.join(golden_dir, f"generator_{tag}.npz"))
     m = json.loads(str(z["meta"]))
-    spec = orc.generator_spec(m["c"], m["c"], 0, "batch")
+    spec = orc.generator_spec(m["c"], m["c"], 0, "batch", upsampler=m.get("upsampler", "Interpolate"))
     P = orc.fill_state(spec, m["seed"])
     keys = orc.trainable_keys(spec)
     for k in keys:

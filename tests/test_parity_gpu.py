@@ -99,9 +99,9 @@ def test_block_vs_reference_golden(golden_dir, tag, dtype):
     assert ref_m
 
 
-def build_generator(c, seed, dtype, norm=nn.BatchNorm2d):
-    spec = orc.generator_spec(c, c, 0, "batch")
-    G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=norm, compute_dtype=dtype)
+def build_generator(c, seed, dtype, norm=nn.BatchNorm2d, upsampler="Interpolate"):
+    spec = orc.generator_spec(c, c, 0, "batch", upsampler=upsampler)
+    G = dxg.Generator(c, c, upsampler, "Uniform", 0, normalizer=norm, compute_dtype=dtype)
     G.load_state_dict(orc.fill_state(spec, seed))
     return G.to(DEV), spec
 
@@ -114,7 +114,7 @@ def build_discriminator(c, h, w, seed, dtype, norm=nn.BatchNorm2d, kind="batch")
 
 
 def _bf16_oracle_generator(m):
-    spec = orc.generator_spec(m["c"], m["c"], 0, "batch")
+    spec = orc.generator_spec(m["c"], m["c"], 0, "batch", upsampler=m.get("upsampler", "Interpolate"))
     P = orc.fill_state(spec, m["seed"])
     x, _ = orc.synthetic_fields(m["n"], m["c"], m["h"], m["w"], m["field_seed"])
     with torch.no_grad():
@@ -122,10 +122,12 @@ def _bf16_oracle_generator(m):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("tag", ["c4_64x64", "c8_40x56"])
+@pytest.mark.parametrize("tag", ["c4_64x64", "c8_40x56", "deconv_c4_19x37", "deconv1x_c4_19x37"])
 def test_generator_vs_reference_golden(golden_dir, tag, dtype):
+    """Interpolate upsampler at two sizes; Deconv / Deconv1x (ConvTranspose2d chain + AvgPool2d + extension,
+    deeplab.py:398-500) on the 19x37 grid they are shape-locked to."""
     z, m = gz(golden_dir, f"generator_{tag}.npz")
-    G, spec = build_generator(m["c"], m["seed"], dtype)
+    G, spec = build_generator(m["c"], m["seed"], dtype, upsampler=m.get("upsampler", "Interpolate"))
     G.train()
     x, y = orc.synthetic_fields(m["n"], m["c"], m["h"], m["w"], m["field_seed"])
     out = G(x.to(DEV))
