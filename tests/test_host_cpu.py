@@ -62,8 +62,11 @@ def test_no_cpu_fallback():
     G = dxg.Generator(4, 4, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         G(torch.zeros(2, 4, 64, 64))
-    with pytest.raises(NotImplementedError):
-        dxg.Generator(4, 4, "Deconv1x", "Uniform", 0, normalizer=nn.BatchNorm2d)
+    Gd = dxg.Generator(4, 4, "Deconv1x", "Uniform", 0, normalizer=nn.BatchNorm2d)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Gd(torch.zeros(2, 4, 19, 37))
+    with pytest.raises(NotImplementedError):   # like the reference: no upsampler of that name (deeplab.py:642)
+        dxg.Generator(4, 4, "Interpolate1x", "Uniform", 0, normalizer=nn.BatchNorm2d)
     with pytest.raises(NotImplementedError):
         dxg.Generator(4, 4, "Interpolate", "Cauchy", 0)
 
