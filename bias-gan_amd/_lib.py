@@ -84,6 +84,8 @@ _SIGS = {
     "bg_bce_logits": [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp],
     "bg_l1_loss_fwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
     "bg_l1_loss_bwd": [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
+    "bg_pixel_loss_fwd": [c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
+    "bg_pixel_loss_bwd": [c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
     "bg_gp_penalty": [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp],
     "bg_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32,
                      c_f32, c_vp],

@@ -93,25 +93,32 @@ __global__ void bce_logits_kernel(const float* x, const float* y, int n, float* 
     if (threadIdx.x == 0) loss[0] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
 }
 
-__global__ void l1_fwd_kernel(const float* p, const float* t, const float* w, long long n, float inv_norm,
+// kind: 0 = |d| (nn.L1Loss), 1 = SmoothL1 with beta = 1 (0.5 d^2 for |d| < 1, |d| - 0.5 beyond), 2 = d^2 (nn.MSELoss)
+__device__ __forceinline__ float pix_loss(int kind, float d) {
+    const float a = fabsf(d);
+    return kind == 0 ? a : (kind == 1 ? (a < 1.f ? 0.5f * d * d : a - 0.5f) : d * d);
+}
+__device__ __forceinline__ float pix_loss_grad(int kind, float d) {
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    return kind == 0 ? sgn : (kind == 1 ? (fabsf(d) < 1.f ? d : sgn) : 2.f * d);
+}
+
+__global__ void l1_fwd_kernel(int kind, const float* p, const float* t, const float* w, long long n, float inv_norm,
                               float* loss) {
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float a = fabsf(p[i] - t[i]);
+        const float a = pix_loss(kind, p[i] - t[i]);
         acc += w ? a * w[i] : a;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_norm);
 }
 
-__global__ void l1_bwd_kernel(const float* p, const float* t, const float* w, long long n, float inv_norm,
+__global__ void l1_bwd_kernel(int kind, const float* p, const float* t, const float* w, long long n, float inv_norm,
                               const float* coef, float* dp) {
     const float k = coef[0] * inv_norm;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float d = p[i] - t[i];
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dp[i] = sgn * (w ? w[i] : 1.f) * k;
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dp[i] = pix_loss_grad(kind, p[i] - t[i]) * (w ? w[i] : 1.f) * k;
 }
 
 __global__ void gp_kernel(const float* g, int N, int C, int HW, float inv_norm, float* loss) {
@@ -189,22 +196,32 @@ extern "C" int bg_bce_logits(const float* x, const float* y, int32_t n, float* l
     return BG_OK;
 }
 
-extern "C" int bg_l1_loss_fwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm, float* loss,
-                              void* stream) {
-    BG_CHECK_ARG(p && t && loss && n > 0, "bg_l1_loss_fwd: bad args");
-    hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(n)), dim3(256), 0, (hipStream_t)stream, p, t, w, (long long)n,
+extern "C" int bg_pixel_loss_fwd(int32_t kind, const float* p, const float* t, const float* w, int64_t n,
+                                 float inv_norm, float* loss, void* stream) {
+    BG_CHECK_ARG(p && t && loss && n > 0 && kind >= 0 && kind <= 2, "bg_pixel_loss_fwd: bad args");
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(n)), dim3(256), 0, (hipStream_t)stream, kind, p, t, w, (long long)n,
                        inv_norm, loss);
     BG_CHECK_LAUNCH("l1_fwd_kernel");
     return BG_OK;
 }
 
-extern "C" int bg_l1_loss_bwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm,
-                              const float* coef, float* dp, void* stream) {
-    BG_CHECK_ARG(p && t && coef && dp && n > 0, "bg_l1_loss_bwd: bad args");
-    hipLaunchKernelGGL(l1_bwd_kernel, dim3(red_grid(n) * 4), dim3(256), 0, (hipStream_t)stream, p, t, w, (long long)n,
-                       inv_norm, coef, dp);
+extern "C" int bg_pixel_loss_bwd(int32_t kind, const float* p, const float* t, const float* w, int64_t n,
+                                 float inv_norm, const float* coef, float* dp, void* stream) {
+    BG_CHECK_ARG(p && t && coef && dp && n > 0 && kind >= 0 && kind <= 2, "bg_pixel_loss_bwd: bad args");
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(red_grid(n) * 4), dim3(256), 0, (hipStream_t)stream, kind, p, t, w,
+                       (long long)n, inv_norm, coef, dp);
     BG_CHECK_LAUNCH("l1_bwd_kernel");
     return BG_OK;
+}
+
+extern "C" int bg_l1_loss_fwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm, float* loss,
+                              void* stream) {
+    return bg_pixel_loss_fwd(0, p, t, w, n, inv_norm, loss, stream);
+}
+
+extern "C" int bg_l1_loss_bwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm,
+                              const float* coef, float* dp, void* stream) {
+    return bg_pixel_loss_bwd(0, p, t, w, n, inv_norm, coef, dp, stream);
 }
 
 extern "C" int bg_gp_penalty(const float* g, int32_t N, int32_t C, int32_t HW, float inv_norm, float* loss,

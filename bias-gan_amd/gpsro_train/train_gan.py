@@ -238,9 +238,14 @@ def main(pargs):
     discriminator = dxg.Discriminator(n_input=nch, os=16, pretrained=False, normalizer=normalizer, input_size=field,
                                       compute_dtype=cdt).to(device)
     criterion_gan = losses.GANLoss(pargs.loss_type_gan, pargs.local_batch_size, device)
-    if pargs.loss_type_regression != "l1":
+    if pargs.loss_type_regression == "l1":                         # train_gan.py:142-152
+        criterion_regression = losses.L1LossWeighted() if pargs.enable_masks else losses.L1Loss()
+    elif pargs.loss_type_regression == "smooth_l1":
+        criterion_regression = losses.SmoothL1Loss()
+    elif pargs.loss_type_regression == "l2":
+        criterion_regression = losses.MSELoss()
+    else:
         raise NotImplementedError("Error, loss {} not implemented.".format(pargs.loss_type_regression))
-    criterion_regression = losses.L1LossWeighted() if pargs.enable_masks else losses.L1Loss()
     g_opt = ph.get_optimizer(generator.parameters(), pargs.optimizer_generator, pargs.start_lr_generator, pargs.adam_eps,
                              pargs.weight_decay)
     d_opt = ph.get_optimizer(discriminator.parameters(), pargs.optimizer_discriminator, pargs.start_lr_discriminator,
@@ -312,7 +317,7 @@ def build_parser():
     AP.add_argument("--adam_eps", type=float, default=1e-8)
     AP.add_argument("--weight_decay", type=float, default=1e-4)
     AP.add_argument("--loss_type_gan", type=str, default="ModifiedMinMax", choices=["ModifiedMinMax", "Wasserstein"])
-    AP.add_argument("--loss_type_regression", type=str, default="l1")
+    AP.add_argument("--loss_type_regression", type=str, default="l1", choices=["l1", "smooth_l1", "l2"])
     AP.add_argument("--loss_weight_gan", type=float, default=1.)
     AP.add_argument("--loss_weight_regression", type=float, default=1.)
     AP.add_argument("--loss_weight_gp", type=float, default=10.)

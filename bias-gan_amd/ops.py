@@ -627,18 +627,22 @@ class BCEWithLogitsFn(torch.autograd.Function):
         return dx * g, None  # N scalars of glue
 
 
+PIXEL_LOSS_KINDS = {"l1": 0, "smooth_l1": 1, "l2": 2}
+
+
 class L1LossFn(torch.autograd.Function):
-    """mean(|p-t| * w) or sum(|p-t| w)/(sum w + eps)  (nn.L1Loss / L1LossWeighted, losses.py:101-112)."""
+    """inv_norm * sum(f(p-t) * w), f = |d| (nn.L1Loss / L1LossWeighted, losses.py:101-112), SmoothL1 (beta 1)
+    or d^2 (nn.SmoothL1Loss / nn.MSELoss, train_gan.py:147-150; L2LossWeighted, losses.py:115-126)."""
 
     @staticmethod
-    def forward(ctx, pred, target, weights, inv_norm: float):
+    def forward(ctx, pred, target, weights, inv_norm: float, kind: int = 0):
         p = pred.contiguous().float()
         t = target.contiguous().float()
         wt = None if weights is None else weights.contiguous().float()
         loss = _f32(1, device=p.device)
-        L.call("bg_l1_loss_fwd", p.data_ptr(), t.data_ptr(), L.ptr(wt), p.numel(), inv_norm, loss.data_ptr())
+        L.call("bg_pixel_loss_fwd", kind, p.data_ptr(), t.data_ptr(), L.ptr(wt), p.numel(), inv_norm, loss.data_ptr())
         ctx.save_for_backward(p, t, wt)
-        ctx.inv_norm = inv_norm
+        ctx.inv_norm, ctx.kind = inv_norm, kind
         return loss.view(())
 
     @staticmethod
@@ -646,9 +650,9 @@ class L1LossFn(torch.autograd.Function):
         p, t, wt = ctx.saved_tensors
         dp = torch.empty_like(p)
         coef = g.reshape(1).float().contiguous()
-        L.call("bg_l1_loss_bwd", p.data_ptr(), t.data_ptr(), L.ptr(wt), p.numel(), ctx.inv_norm, coef.data_ptr(),
-               dp.data_ptr())
-        return dp, None, None, None
+        L.call("bg_pixel_loss_bwd", ctx.kind, p.data_ptr(), t.data_ptr(), L.ptr(wt), p.numel(), ctx.inv_norm,
+               coef.data_ptr(), dp.data_ptr())
+        return dp, None, None, None, None
 
 
 def gp_penalty_value(grad_nchw: torch.Tensor) -> torch.Tensor:

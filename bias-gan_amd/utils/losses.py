@@ -7,30 +7,56 @@ import torch
 from .. import ops
 
 
-class _L1:
+class _PixelMean:
+    def __init__(self, kind):
+        self.kind = ops.PIXEL_LOSS_KINDS[kind]
+
     def __call__(self, prediction, target):
-        return ops.L1LossFn.apply(prediction, target, None, 1.0 / prediction.numel())
+        return ops.L1LossFn.apply(prediction, target, None, 1.0 / prediction.numel(), self.kind)
 
 
 def L1Loss():
     """Stand-in for nn.L1Loss() (mean absolute error), train_gan.py:146."""
-    return _L1()
+    return _PixelMean("l1")
 
 
-class L1LossWeighted:
-    """mean(|p-t|*w), or sum(|p-t|*w)/(sum(w)+eps) when normalize (losses.py:101-112)."""
+def SmoothL1Loss():
+    """Stand-in for nn.SmoothL1Loss() (beta = 1), train_gan.py:148."""
+    return _PixelMean("smooth_l1")
 
-    def __init__(self, normalize=False, eps=1.e-8, smooth=False):
-        if smooth:
-            raise NotImplementedError("SmoothL1 is not on the HIP path")
-        self.eps = eps
-        self.normalize = normalize
+
+def MSELoss():
+    """Stand-in for nn.MSELoss(), train_gan.py:150."""
+    return _PixelMean("l2")
+
+
+class _Weighted:
+    kind = 0
 
     def __call__(self, prediction, target, weights):
         if self.normalize:
-            s = ops.L1LossFn.apply(prediction, target, weights, 1.0)
+            s = ops.L1LossFn.apply(prediction, target, weights, 1.0, self.kind)
             return s / (torch.sum(weights) + self.eps)
-        return ops.L1LossFn.apply(prediction, target, weights, 1.0 / prediction.numel())
+        return ops.L1LossFn.apply(prediction, target, weights, 1.0 / prediction.numel(), self.kind)
+
+
+class L1LossWeighted(_Weighted):
+    """mean(|p-t|*w), or sum(|p-t|*w)/(sum(w)+eps) when normalize; smooth=True swaps in SmoothL1
+    (losses.py:101-112)."""
+
+    def __init__(self, normalize=False, eps=1.e-8, smooth=False):
+        self.kind = ops.PIXEL_LOSS_KINDS["smooth_l1" if smooth else "l1"]
+        self.eps = eps
+        self.normalize = normalize
+
+
+class L2LossWeighted(_Weighted):
+    """mean((p-t)^2*w), or the weight-normalised sum (losses.py:115-126)."""
+
+    def __init__(self, normalize=False, eps=1.e-8):
+        self.kind = ops.PIXEL_LOSS_KINDS["l2"]
+        self.eps = eps
+        self.normalize = normalize
 
 
 class GANLoss:

@@ -234,6 +234,13 @@ int bg_l1_loss_fwd(const float* p, const float* t, const float* w, int64_t n, fl
 /* dp = sign(p-t) * w * coef[0] * inv_norm   (coef: device scalar = upstream gradient). */
 int bg_l1_loss_bwd(const float* p, const float* t, const float* w, int64_t n, float inv_norm, const float* coef,
                    float* dp, void* stream);
+/* The other regression criteria of train_gan.py:142-152 on the same flat arrays.  kind: 0 = |d|
+ * (= bg_l1_loss_*), 1 = nn.SmoothL1Loss (beta = 1), 2 = nn.MSELoss; d = p - t; weights as above
+ * (losses.py:101-128: L1LossWeighted(smooth=...), L2LossWeighted). */
+int bg_pixel_loss_fwd(int32_t kind, const float* p, const float* t, const float* w, int64_t n, float inv_norm,
+                      float* loss, void* stream);
+int bg_pixel_loss_bwd(int32_t kind, const float* p, const float* t, const float* w, int64_t n, float inv_norm,
+                      const float* coef, float* dp, void* stream);
 /* loss += inv_norm * sum over (n,pixel) of (||g[n,:,pixel]||_2 - 1)^2, g NCHW fp32 (caller zeroes loss). */
 int bg_gp_penalty(const float* g, int32_t N, int32_t C, int32_t HW, float inv_norm, float* loss, void* stream);
 

@@ -614,3 +614,25 @@ def test_conv_transpose_via_conv_entry_points(dtype, pad, op):
     torch.cuda.synchronize()
     assert_close(xd.grad.cpu(), xr.grad, tol(dtype) * 2, "dx")
     assert_close(m.weight.grad.cpu(), wr.grad, 5e-4 if dtype == torch.float32 else 2e-2, "dw")
+
+
+@pytest.mark.parametrize("kind", ["l1", "smooth_l1", "l2"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_pixel_losses(kind, weighted):
+    """nn.L1Loss / nn.SmoothL1Loss / nn.MSELoss and the weighted forms (train_gan.py:142-152, losses.py:101-126)."""
+    from bias_gan_amd.utils import losses as bl
+    torch.manual_seed(3)
+    p = (torch.randn(2, 5, 9, 11) * 1.5).requires_grad_(True)
+    t, w = torch.randn(2, 5, 9, 11), torch.rand(2, 5, 9, 11)
+    f = {"l1": F.l1_loss, "smooth_l1": F.smooth_l1_loss, "l2": F.mse_loss}[kind]
+    ref = (f(p, t, reduction="none") * w).mean() if weighted else f(p, t)
+    ref.backward()
+    pd = p.detach().to(DEV).requires_grad_(True)
+    if weighted:
+        crit = bl.L2LossWeighted() if kind == "l2" else bl.L1LossWeighted(smooth=kind == "smooth_l1")
+        got = crit(pd, t.to(DEV), w.to(DEV))
+    else:
+        got = {"l1": bl.L1Loss, "smooth_l1": bl.SmoothL1Loss, "l2": bl.MSELoss}[kind]()(pd, t.to(DEV))
+    got.backward()
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert_close(pd.grad.cpu(), p.grad, 1e-5, "dp")
