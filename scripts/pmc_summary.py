@@ -8,7 +8,8 @@ FAMILY = {  # kernel symbol fragment -> C-ABI entry points it implements
     "gemm_conv_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data",
     "gemm_conv_dma_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data",
     "wgrad_kernel": "bg_conv2d_bwd_weight",
-    "dw_fwd": "bg_dwconv3x3_fwd(+stride-1 bwd_data)",
+    "dw_s1_kernel": "bg_dwconv3x3_fwd+bg_dwconv3x3_bwd_data(stride 1, dilation 1)",
+    "dw_fwd": "bg_dwconv3x3_fwd(+stride-1 bwd_data, other strides/dilations)",
     "dw_bwd_data": "bg_dwconv3x3_bwd_data(stride 2)",
     "dw_bwd_weight": "bg_dwconv3x3_bwd_weight",
     "norm_act_fwd": "bg_norm_act_fwd",
