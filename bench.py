@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write (entry, flops, bytes, ms) of every launch of the profile step")
     return ap.parse_args()
 
 
@@ -190,6 +191,10 @@ def main():
         torch.cuda.synchronize()
         trainer._side = side
         recs, L.PROFILE = L.PROFILE, None
+        if args.dump_launches:
+            with open(args.dump_launches, "w") as f:
+                for name, flops, e0, e1, nbytes in recs:
+                    f.write(f"{name} {flops:.0f} {nbytes:.0f} {e0.elapsed_time(e1):.5f}\n")
         fam = {}
         for name, flops, e0, e1, nbytes in recs:
             f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])

@@ -131,6 +131,7 @@ def _norm_kind(m: nn.Module) -> str:
 
 import os as _os
 _FUSED_STATS = _os.environ.get("BGAMD_NO_FUSED_STATS") is None  # A/B switch
+_STAT_COPIES = int(_os.environ.get("BGAMD_STAT_COPIES", "1"))     # accumulator copies the conv tiles spread over (measured: 1 is fastest)
 
 
 def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
@@ -141,7 +142,7 @@ def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
     stats = None
     if isinstance(m, nn.BatchNorm2d) and m.training and dense.bias is None and _FUSED_STATS:
         kp = owner.arena().by_param[id(dense.weight)].phys_shape[0]
-        stats = StatsPool.get(x.device).take(2, kp)
+        stats = StatsPool.get(x.device).take(2, _STAT_COPIES, kp)
     y = conv(x, stats) if stats is not None else conv(x)
     return apply_norm(owner, m, y, res=res, act=act, stats=stats)
 

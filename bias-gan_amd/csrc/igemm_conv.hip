@@ -47,6 +47,7 @@ struct GemmConvParams {
     int tiles_c, tiles_p;
     double* stat_sum;  // optional per-output-channel sum / sum of squares of the STORED outputs
     double* stat_sq;   // (BatchNorm statistics fused into the epilogue); NULL = off
+    int stat_copies;   // accumulator copies [copies][NO] (power of two): blocks spread over them by id
     int CKp;       // K stride of one tap inside the (zero-padded) weight copy
     int in_bytes;  // exact extent of the activation operand (buffer-load range check)
     int w_bytes;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wav
 // P.stat_sum set it also reduces sum(y) and sum(y^2) of the values AS STORED
 // (after rounding to T) over the tile's 128 pixels: 16-lane shuffle tree, the two
 // pixel-waves are combined through LDS, one fp64 atomic per channel per tile.
-template <typename T>
+template <typename T, int TCH = TILE>
 __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&acc)[4][4], long long p_base, int c_base,
                                               int wave_c, int wave_p, int lane, char* smem) {
     T* out = reinterpret_cast<T*>(P.out);
@@ -170,22 +171,25 @@ __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&a
                 s2[i][e] = b;
             }
         __syncthreads();  // every wave is done reading the staging ring: reuse it
-        float* red = reinterpret_cast<float*>(smem);  // [wave_p][128 channels][2]
+        float* red = reinterpret_cast<float*>(smem);  // [wave_p][TCH channels][2]
         if (r16 == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int cl = wave_c * 64 + i * 16 + q * 4 + e;
-                    red[(wave_p * TILE + cl) * 2 + 0] = s1[i][e];
-                    red[(wave_p * TILE + cl) * 2 + 1] = s2[i][e];
+                    red[(wave_p * TCH + cl) * 2 + 0] = s1[i][e];
+                    red[(wave_p * TCH + cl) * 2 + 1] = s2[i][e];
                 }
         }
         __syncthreads();
         const int t = threadIdx.x;
-        if (t < TILE && c_base + t < P.NO) {
-            atomicAdd(P.stat_sum + c_base + t, (double)(red[t * 2] + red[(TILE + t) * 2]));
-            atomicAdd(P.stat_sq + c_base + t, (double)(red[t * 2 + 1] + red[(TILE + t) * 2 + 1]));
+        if (t < TCH && c_base + t < P.NO) {
+            // every pixel tile adds into the same NO addresses; same-address atomics serialise at the
+            // memory side, so the blocks are spread over `copies` accumulators (summed by the consumer)
+            const long long o = (long long)(blockIdx.x & (P.stat_copies - 1)) * P.NO + c_base + t;
+            atomicAdd(P.stat_sum + o, (double)(red[t * 2] + red[(TCH + t) * 2]));
+            atomicAdd(P.stat_sq + o, (double)(red[t * 2 + 1] + red[(TCH + t) * 2 + 1]));
         }
     }
 }
@@ -367,17 +371,25 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BKB, int NBUF>
-__global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams P) {
+// TCH = out-channel rows of the tile: 128 (4 waves) or 256 (8 waves, each still a 64x64 sub-tile).
+// The kernel is bound by operand delivery into LDS, not by the MFMAs (an ablation build without the
+// MFMAs runs as fast, one without the loads 1.5-1.8x faster); 256 x 128 moves 25 % fewer operand bytes
+// per FLOP than 128 x 128 and puts 16 waves on a CU (2 workgroups x 72 KiB of LDS).
+template <typename T, int BKB, int NBUF, int TCH>
+__global__ __launch_bounds__(TCH * 2) void gemm_conv_dma_kernel(GemmConvParams P) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BK = BKB / ES;
     constexpr int CPR = BKB / 16;   // chunks per row
     constexpr int RPG = 64 / CPR;   // tile rows covered by one wave-wide DMA (1 KiB)
-    constexpr int NG = 32 / RPG;    // DMAs per operand per wave per K-step (a wave stages 32 rows)
-    constexpr int GROUP = 2 * NG;   // VMEM ops per wave per K-step
-    constexpr int TILE_BYTES = TILE * BKB;
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int NW = TCH / 32;    // waves per workgroup
+    constexpr int ROWS_A = TCH / NW, ROWS_B = TILE / NW;  // tile rows a wave stages per operand: 32 and 32 | 16
+    constexpr int NGA = ROWS_A / RPG, NGB = ROWS_B / RPG;  // DMAs per wave per K-step
+    constexpr int NG = NGA > NGB ? NGA : NGB;
+    constexpr int GROUP = NGA + NGB;  // VMEM ops per wave per K-step
+    constexpr int TILE_BYTES = TCH * BKB;               // A (weight) rows of one stage
+    constexpr int STAGE_BYTES = (TCH + TILE) * BKB;
     constexpr int DIST = NBUF - 1;  // K-steps in flight ahead of the MFMAs
+    static_assert(NGA >= 1 && NGB >= 1, "a wave stages at least one DMA per operand");
     static_assert(DIST == 2 || DIST == 3, "counted waits are written for 2 or 3 K-steps of prefetch");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -394,22 +406,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
     }
     const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
     const long long p_base = (long long)tile_p * TILE;
-    const int c_base = tile_c * TILE;
+    const int c_base = tile_c * TCH;
     const int RS = P.KH * P.KW;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.in), 0, P.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.w), 0, P.w_bytes, 0x00020000);
 
     const int lr = lane / CPR, lc = lane % CPR;
-    int pix_base[NG], pix_n[NG], pix_h[NG], pix_w[NG], w_base[NG], chk16[NG];
-    bool pix_ok[NG], tail_cut[NG];  // tail_cut: see gemm_conv_kernel
+    int pix_base[NGB], pix_n[NGB], pix_h[NGB], pix_w[NGB], w_base[NGA], chk16[NGB];
+    bool pix_ok[NGB], tail_cut[NGB];  // tail_cut: see gemm_conv_kernel
     const bool direct = !P.transposed || P.stride == 1;
     const int sgn = P.transposed ? -1 : 1;
+    auto src_chunk = [&](int row) { return ((BKB == 64) ? (lc ^ ((0 - (row >> 2)) & 3)) : (lc ^ ((row >> 1) & 7))) * 16; };
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int row = wave * 32 + g * RPG + lr;  // row inside the 128-row tile (same for A and B)
-        const int chk = (BKB == 64) ? (lc ^ ((0 - (row >> 2)) & 3)) : (lc ^ ((row >> 1) & 7));
-        chk16[g] = chk * 16;
+    for (int g = 0; g < NGA; ++g) {
+        const int row = wave * ROWS_A + g * RPG + lr;  // weight row inside the tile
+        const int co = c_base + row;
+        w_base[g] = co < P.NO ? co * RS * P.CKp * ES + src_chunk(row) : OOB;
+    }
+#pragma unroll
+    for (int g = 0; g < NGB; ++g) {
+        const int row = wave * ROWS_B + g * RPG + lr;  // pixel row inside the tile
+        chk16[g] = src_chunk(row);
         const long long p = p_base + row;
         pix_ok[g] = p < P.M;
         const unsigned pp = pix_ok[g] ? (unsigned)p : 0u;
@@ -427,23 +445,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
             pix_w[g] = ow + P.pad;
         }
         pix_base[g] = (((int)n * P.IH + pix_h[g]) * P.IW + pix_w[g]) * P.ldi * ES + chk16[g];
-        const int co = c_base + row;
-        w_base[g] = co < P.NO ? co * RS * P.CKp * ES + chk16[g] : OOB;
     }
 
     const int ksteps_per_tap = (P.CK + BK - 1) / BK;
     const int KT = RS * ksteps_per_tap;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) tail_cut[g] = (ksteps_per_tap - 1) * BK + chk16[g] / ES >= P.CK;
+    for (int g = 0; g < NGB; ++g) tail_cut[g] = (ksteps_per_tap - 1) * BK + chk16[g] / ES >= P.CK;
 
     int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
-    int va[NG], vb[NG];
+    int va[NGA], vb[NGB];
     auto start_tap = [&]() {
         const int dh = sgn * l_tap_r * P.dil, dw_ = sgn * l_tap_s * P.dil;
         const int tap_delta = (dh * P.IW + dw_) * P.ldi * ES;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            va[g] = w_base[g] == OOB ? OOB : w_base[g] + l_tap * P.CKp * ES;
+        for (int g = 0; g < NGA; ++g) va[g] = w_base[g] == OOB ? OOB : w_base[g] + l_tap * P.CKp * ES;
+#pragma unroll
+        for (int g = 0; g < NGB; ++g) {
             if (direct) {
                 const int ih = pix_h[g] + dh, iw = pix_w[g] + dw_;
                 const bool ok = pix_ok[g] && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
@@ -459,14 +476,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
     };
     auto issue = [&](int buf) {
         if (l_ks == 0) start_tap();
-        char* stage = smem + buf * STAGE_BYTES + wave * 32 * BKB;
+        char* stage_a = smem + buf * STAGE_BYTES + wave * ROWS_A * BKB;
+        char* stage_b = smem + buf * STAGE_BYTES + TILE_BYTES + wave * ROWS_B * BKB;
         const bool last = l_ks == ksteps_per_tap - 1;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            dma16(rs_w, stage + g * RPG * BKB, va[g]);
-            dma16(rs_in, stage + TILE_BYTES + g * RPG * BKB, (last && tail_cut[g]) ? OOB : vb[g]);
-            va[g] += BKB;
-            vb[g] += BKB;
+        for (int g = 0; g < NG; ++g) {  // A and B DMAs interleaved
+            if (g < NGA) {
+#ifdef ABL_NO_LOAD   // ablation: without the global->LDS half (every DMA out of range: no memory traffic)
+                dma16(rs_w, stage_a + g * RPG * BKB, OOB);
+#elif defined(ABL_HOT_LOAD)   // ablation: every DMA hits the same few KB (L1/L2-resident operands)
+                dma16(rs_w, stage_a + g * RPG * BKB, va[g] == OOB ? OOB : (va[g] & 0xFFFF));
+#else
+                dma16(rs_w, stage_a + g * RPG * BKB, va[g]);
+#endif
+                va[g] += BKB;
+            }
+            if (g < NGB) {
+#ifdef ABL_NO_LOAD
+                dma16(rs_in, stage_b + g * RPG * BKB, OOB);
+#elif defined(ABL_HOT_LOAD)
+                dma16(rs_in, stage_b + g * RPG * BKB, vb[g] == OOB ? OOB : (vb[g] & 0xFFFF));
+#else
+                dma16(rs_in, stage_b + g * RPG * BKB, (last && tail_cut[g]) ? OOB : vb[g]);
+#endif
+                vb[g] += BKB;
+            }
         }
         if (++l_ks == ksteps_per_tap) {
             l_ks = 0;
@@ -495,12 +529,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_dma_kernel(GemmConvParams 
         // stage kt+2: its ring slot was last read in iteration kt-1, which every wave has left
         if (kt + DIST < KT) issue(nbuf);
         const char* sA = smem + buf * STAGE_BYTES;
+#ifndef ABL_NO_MMA   // ablation builds (scripts/ablate_conv.sh): what the K loop costs without its MFMA/LDS-read half
         mma_slab<T, BKB>(sA, sA + TILE_BYTES, wave_c, wave_p, lane, acc);
+#endif
         buf = (buf + 1 == NBUF) ? 0 : buf + 1;
         nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
     }
 
-    conv_epilogue<T>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
+    conv_epilogue<T, TCH>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
 }
 
 // ------------------------------------------------------------------ wgrad ----
@@ -784,7 +820,12 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     }
     P.in_bytes = (int)in_bytes;
     P.w_bytes = (int)w_bytes;
-    P.tiles_c = (P.NO + TILE - 1) / TILE;
+    static const int dma_mode = getenv("BGAMD_DMA") ? atoi(getenv("BGAMD_DMA")) : 1;  // 0: register staging; 1: 3-stage ring, 64-byte rows (default); 2: 128-byte rows where they pad less; 3: 4-stage ring
+    static const int tch_max = getenv("BGAMD_TCH") ? atoi(getenv("BGAMD_TCH")) : 256;  // A/B switch: 128 = old tile
+    // 256 out-channel rows per tile wherever that does not add padding (NO <= 128 stays on 128 x 128)
+    const bool tall = dma_mode == 1 && tch_max >= 256 && P.NO > TILE;
+    const int tch = tall ? 256 : TILE;
+    P.tiles_c = (P.NO + tch - 1) / tch;
     P.tiles_p = (int)((P.M + TILE - 1) / TILE);
     const long long nblk = (long long)P.tiles_c * P.tiles_p;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
@@ -797,19 +838,27 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     const int pad64 = (P.CK + bk64 - 1) / bk64 * bk64, pad128 = (P.CK + bk128 - 1) / bk128 * bk128;
     bool use128 = pad128 <= pad64 + pad64 / 32;
     if (const char* e = getenv("BGAMD_BKB")) use128 = atoi(e) == 128;  // tuning knob
-    static const int dma_mode = getenv("BGAMD_DMA") ? atoi(getenv("BGAMD_DMA")) : 1;  // 0: register staging; 1: 3-stage ring, 64-byte rows (default); 2: 128-byte rows where they pad less; 3: 4-stage ring
     if (dma_mode) {
-        if (use128 && dma_mode == 2) {
+        if (tall) {
+            const size_t sh = 3 * (256 + TILE) * 64;  // 72 KiB
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 64, 3, 256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                once = true;
+            }
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3, 256>), dim3((unsigned)nblk), dim3(512), sh, st, P);
+        } else if (use128 && dma_mode == 2) {
             const size_t sh = 3 * 2 * TILE * 128;  // 96 KiB
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 128, 3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 128, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 128, 3, TILE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 128, 3, TILE>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
         } else if (dma_mode == 3) {
             const size_t sh = 4 * 2 * TILE * 64;  // 64 KiB
-            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 4>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 4, TILE>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
         } else {
             const size_t sh = 3 * 2 * TILE * 64;  // 48 KiB
-            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3, TILE>), dim3((unsigned)nblk), dim3(NTHREADS), sh, st, P);
         }
         BG_CHECK_LAUNCH("gemm_conv_dma_kernel");
         return BG_OK;
@@ -844,11 +893,12 @@ extern "C" int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w
 }
 
 extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum,
-                                   double* sumsq, void* stream) {
+                                   double* sumsq, int32_t copies, void* stream) {
     int rc = check_conv_desc(d, "bg_conv2d_fwd_stats");
     if (rc) return rc;
     BG_CHECK_ARG(x && w && y && sum && sumsq && aligned16(x) && aligned16(w) && aligned16(y),
                  "bg_conv2d_fwd_stats: null/unaligned pointer");
+    BG_CHECK_ARG(copies >= 1 && copies <= 64 && (copies & (copies - 1)) == 0, "bg_conv2d_fwd_stats: copies must be a power of two <= 64");
     GemmConvParams P{};
     P.in = x; P.w = w; P.out = y; P.bias = nullptr;
     P.N = d->N; P.IH = d->H; P.IW = d->W; P.OH = d->Ho; P.OW = d->Wo;
@@ -856,7 +906,7 @@ extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const v
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
     P.transposed = 0;
     P.M = (long long)d->N * d->Ho * d->Wo;
-    P.stat_sum = sum; P.stat_sq = sumsq;
+    P.stat_sum = sum; P.stat_sq = sumsq; P.stat_copies = copies;
     if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
     return launch_gemm_conv<float>(P, (hipStream_t)stream);
 }

@@ -282,6 +282,7 @@ struct EwParams {
     float* rmean; float* rvar;      // running statistics (batch norm, groups == 1) or NULL
     float* mean_out; float* rstd_out;
     int gx, gy;
+    int stat_copies;  // sum/sumsq are [copies][groups*C] partial accumulators (conv epilogue), 1 = plain
 };
 
 template <typename T>
@@ -309,8 +310,13 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const long long i = (long long)g * P.C + c + e;
-            const double m = P.sum[i] * inv_n;
-            double var = P.sumsq[i] * inv_n - m * m;  // the cancellation-prone step stays in fp64
+            double su = P.sum[i], sq = P.sumsq[i];
+            for (int k = 1; k < P.stat_copies; ++k) {
+                su += P.sum[(long long)k * gridDim.z * P.C + i];
+                sq += P.sumsq[(long long)k * gridDim.z * P.C + i];
+            }
+            const double m = su * inv_n;
+            double var = sq * inv_n - m * m;  // the cancellation-prone step stays in fp64
             if (var < 0.0 || P.rows_per_group == 1) var = 0.0;
             const float r = rsqrtf((float)var + P.eps);
             const float gm = P.gamma ? P.gamma[c + e] : 1.f;
@@ -631,8 +637,9 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
                                      const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, float* mean, float* rstd, const void* res,
                                      int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
-                                     int32_t act, void* stream) {
+                                     int32_t act, int32_t stat_copies, void* stream) {
     int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_fwd_stats");
+    BG_CHECK_ARG(stat_copies >= 1 && stat_copies <= 64, "bg_norm_act_fwd_stats: bad stat_copies");
     if (rc) return rc;
     CHECK_LD(ldx, "bg_norm_act_fwd_stats");
     CHECK_LD(ldy, "bg_norm_act_fwd_stats");
@@ -651,7 +658,7 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd_stats: too many groups");
     EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
                sum, sumsq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd};
-    P.gx = t.gx; P.gy = t.gy;
+    P.gx = t.gx; P.gy = t.gy; P.stat_copies = stat_copies;
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_fwd_kernel(stats)");

@@ -208,9 +208,11 @@ class Conv2dFn(torch.autograd.Function):
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
         if stats is not None:
-            assert bslot is None and stats.shape == (2, kp) and stats.dtype == torch.float64
+            # stats: fp64 [2, copies, kp] (copies a power of two): the tiles spread their atomics over the copies
+            assert bslot is None and stats.dim() == 3 and stats.shape[0] == 2 and stats.shape[2] == kp
+            assert stats.dtype == torch.float64
             L.call("bg_conv2d_fwd_stats", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr(), stats[0].data_ptr(),
-                   stats[1].data_ptr())
+                   stats[1].data_ptr(), stats.shape[1])
         else:
             L.call("bg_conv2d_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot),
                    None if bslot is None else arena.master_ptr(bslot), y.data_ptr())
@@ -364,7 +366,7 @@ class NormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum,
                 pre_stats=None):
-        """pre_stats: fp64 [2, C] sums already produced by the convolution's epilogue
+        """pre_stats: fp64 [2, copies, C] partial sums already produced by the convolution's epilogue
         (bg_conv2d_fwd_stats); skips the separate statistics pass."""
         x = nhwc(x)
         n, h, w, c = x.shape
@@ -379,8 +381,9 @@ class NormActFn(torch.autograd.Function):
         gptr = None if gslot is None else arena.master_ptr(gslot)
         bptr = None if bslot is None else arena.master_ptr(bslot)
         if kind != "identity" and use_batch_stats:
+            copies = 1
             if pre_stats is not None and groups == 1:
-                s = pre_stats.view(2, 1, c)
+                s, copies = pre_stats, pre_stats.shape[1]      # [2, copies, C] partial accumulators
             else:
                 s = _f64(2, groups, c, device=dev)
                 L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
@@ -389,7 +392,8 @@ class NormActFn(torch.autograd.Function):
             # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
             L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
                    momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
+                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act),
+                   copies)
         else:
             if kind != "identity":  # BatchNorm in eval mode: affine from the running statistics
                 mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)

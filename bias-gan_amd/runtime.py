@@ -56,7 +56,7 @@ class StatsPool:
     instead of one torch.zeros launch per normalisation layer and direction (~600 per step)."""
     _pools = {}
 
-    def __init__(self, device, n=1 << 21):
+    def __init__(self, device, n=1 << 22):
         self.buf = torch.zeros(n, dtype=torch.float64, device=device)
         self.used = 0
 

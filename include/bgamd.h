@@ -74,11 +74,13 @@ typedef struct bg_conv_desc {
 
 /* y = conv(x, w) (+ bias[Cout], fp32, may be NULL).  w: K-padded KRSC copy, dtype = d->dtype. */
 int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
-/* Same as bg_conv2d_fwd without bias, and additionally sum[c] += sum_pixels y, sumsq[c] += sum_pixels y^2
- * of the outputs as stored (fp64 [Cout], caller zeroes): the batch statistics of the BatchNorm that
- * follows the convolution, taken from the accumulators instead of re-reading y (replaces bg_norm_stats). */
+/* Same as bg_conv2d_fwd without bias, and additionally sum[.][c] += sum_pixels y, sumsq[.][c] += sum_pixels y^2
+ * of the outputs as stored (fp64, caller zeroes): the batch statistics of the BatchNorm that follows
+ * the convolution, taken from the accumulators instead of re-reading y (replaces bg_norm_stats).
+ * sum/sumsq are [copies][Cout] (copies a power of two): workgroups spread their atomics over the copies
+ * (same-address atomics serialise); the statistic is the sum over copies. */
 int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum, double* sumsq,
-                        void* stream);
+                        int32_t copies, void* stream);
 /* dx = conv_transpose(dy, w).  wt: K-padded CRSK copy of the weights.  Overwrites dx. */
 int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
 /* dw += x (*) dy, dw fp32 KRSC (accumulated with float atomics; caller zeroes it
@@ -137,13 +139,15 @@ int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const 
 int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
                     const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
                     int32_t act, void* stream);
-/* bg_norm_finalize + bg_norm_act_fwd in ONE launch (training-mode statistics): every thread derives
+/* (stat_copies: sum/sumsq hold that many partial accumulators [copies][groups*C], see bg_conv2d_fwd_stats.)
+ * bg_norm_finalize + bg_norm_act_fwd in ONE launch (training-mode statistics): every thread derives
  * the affine of its channels from the fp64 sums; the first row-block of each group also writes
  * mean/rstd (fp32 [groups,C]) and applies the running-statistics update. */
 int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, const double* sum, const double* sumsq,
                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* rstd, const void* res, int32_t ldres, void* y,
-                          int32_t ldy, int64_t rows, int32_t C, int32_t groups, int32_t act, void* stream);
+                          int32_t ldy, int64_t rows, int32_t C, int32_t groups, int32_t act, int32_t stat_copies,
+                          void* stream);
 /* Backward pass 1: g = dy * act'(y);  s1[g,c] += sum g, s2[g,c] += sum g*xhat
  * (fp64, caller zeroes) with xhat = (x-mean)*rstd.  y == NULL with act != 0 (layers WITHOUT a
  * residual): the LeakyReLU branch is taken from the recomputed pre-activation

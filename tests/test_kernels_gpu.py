@@ -463,12 +463,33 @@ def test_conv_fwd_fused_statistics(dtype):
     xb, xv = to_nhwc(x, dtype)
     wpk, _ = pack(krsc(wt, dtype), dtype)
     yb = torch.zeros(n, ho, wo, up(cout, dtype), dtype=dtype, device=DEV)
-    st = torch.zeros(2, up(cout, dtype), dtype=torch.float64, device=DEV)
-    L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr())
-    y = yb.double()
-    assert_close(from_nhwc(yb, cout), F.conv2d(x, wt, None, 1, 1, 1), tol(dtype), "fwd")
-    assert_close(st[0].cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
-    assert_close(st[1].cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
+    y = None
+    for copies in (1, 4):   # partial accumulators: the statistic is the sum over the copies
+        st = torch.zeros(2, copies, up(cout, dtype), dtype=torch.float64, device=DEV)
+        L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
+               copies)
+        y = yb.double()
+        assert_close(from_nhwc(yb, cout), F.conv2d(x, wt, None, 1, 1, 1), tol(dtype), "fwd")
+        assert_close(st[0].sum(0).cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
+        assert_close(st[1].sum(0).cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
+        if copies > 1:
+            assert (st[0] != 0).any(dim=1).sum().item() > 1, "every tile used the same accumulator copy"
+    # the consumer sums the copies: identical result from [1, C] and from the same sums split over 4 copies
+    c = up(cout, dtype)
+    rows = n * ho * wo
+    outs = []
+    for copies in (1, 4):
+        ss = torch.zeros(2, copies, c, dtype=torch.float64, device=DEV)
+        ss[:, 0] = st.sum(1)
+        if copies > 1:
+            ss[:, 1], ss[:, 0] = ss[:, 0] * 0.25, ss[:, 0] * 0.75
+        mean, rstd = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        o = torch.zeros_like(yb)
+        L.call("bg_norm_act_fwd_stats", L.dt(dtype), yb.data_ptr(), c, ss[0].data_ptr(), ss[1].data_ptr(), None, None, 1e-5,
+               0.1, None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, o.data_ptr(), c, rows, c, 1, 1, copies)
+        outs.append((o.float().cpu(), mean.cpu(), rstd.cpu()))
+    for a, b in zip(*outs):
+        assert_close(b, a, 1e-6, "norm from partial accumulators")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -496,7 +517,7 @@ def test_norm_act_fused_finalize_matches_split(dtype, mode):
         if fused:
             L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), c, s.data_ptr(), ss.data_ptr(), L.ptr(gamma), L.ptr(beta),
                    1e-5, 0.1, L.ptr(rm), L.ptr(rvv), mean.data_ptr(), rstd.data_ptr(), rv.data_ptr(), c, y.data_ptr(), c,
-                   rows, c, groups, 1)
+                   rows, c, groups, 1, 1)
         else:
             L.call("bg_norm_finalize", s.data_ptr(), ss.data_ptr(), rows // groups, groups, c, L.ptr(gamma), L.ptr(beta),
                    1e-5, 0.1, L.ptr(rm), L.ptr(rvv), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
@@ -548,7 +569,7 @@ def test_norm_act_bwd_sign_recomputed_from_x(dtype, mode):
     mean, rstd = f32(groups, c), f32(groups, c)
     y = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
     L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), c, s.data_ptr(), ss.data_ptr(), L.ptr(gamma), L.ptr(beta), 1e-5, 0.1,
-           None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, y.data_ptr(), c, rows, c, groups, 1)
+           None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, y.data_ptr(), c, rows, c, groups, 1, 1)
     out = {}
     for with_y in (True, False):
         yp = y.data_ptr() if with_y else None
