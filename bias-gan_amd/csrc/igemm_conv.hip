@@ -102,6 +102,18 @@ __device__ __forceinline__ void mma_slab(const char* sA, const char* sB, int wav
     }
 }
 
+// Sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane of the row: four
+// VALU adds with a row-rotate modifier instead of four ds_bpermute round trips through the LDS.
+__device__ __forceinline__ float row16_sum(float v) {
+#define BG_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+    v += BG_ROR(v, 8);
+    v += BG_ROR(v, 4);
+    v += BG_ROR(v, 2);
+    v += BG_ROR(v, 1);
+#undef BG_ROR
+    return v;
+}
+
 // Epilogue shared by both staging variants.  A lane holds, per accumulator, 4
 // consecutive output channels of one pixel -> 8/16-byte NHWC stores.  With
 // P.stat_sum set it also reduces sum(y) and sum(y^2) of the values AS STORED
@@ -161,14 +173,8 @@ __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&a
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float a = s1[i][e], b = s2[i][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
-                }
-                s1[i][e] = a;
-                s2[i][e] = b;
+                s1[i][e] = row16_sum(s1[i][e]);
+                s2[i][e] = row16_sum(s2[i][e]);
             }
         __syncthreads();  // every wave is done reading the staging ring: reuse it
         float* red = reinterpret_cast<float*>(smem);  // [wave_p][TCH channels][2]
