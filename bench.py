@@ -108,6 +108,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    if os.environ.get("BGAMD_REHEARSE_ONE_GPU"):   # rehearsal of the N > 1 path on a one-GPU box: every rank on
+        local_rank = 0                              # device 0, gloo instead of RCCL (which refuses duplicate devices)
+        os.environ["LOCAL_RANK"] = "0"
+        os.environ.setdefault("BGAMD_DIST_BACKEND", "gloo")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

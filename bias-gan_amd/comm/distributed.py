@@ -98,7 +98,7 @@ class comm(object):
         if "RANK" in os.environ and "WORLD_SIZE" in os.environ and mode != "dummy":
             # launched by torch.distributed.run: one process per GPU, RCCL over xGMI
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("BGAMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if torch.cuda.is_available():
                 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
             if not dist.is_initialized():

@@ -691,8 +691,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const bool pv = row_p[i] < span;
+#ifdef ABL_W_NO_LOAD
+            ra[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, OOB, 0, 0));
+#else
             ra[i].v = __builtin_bit_cast(typename Elem<T>::vec_t,
                                          __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (pv && co_ok) ? off_dy[i] : OOB, 0, 0));
+#endif
             int ox = OOB;
             if (pv && ci_ok) {
                 const int ih = r_oh[i] * P.stride - P.pad + r * P.dil;
@@ -700,6 +704,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
                 if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
                     ox = (((r_n[i] * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC) * ES;
             }
+#ifdef ABL_W_NO_LOAD
+            ox = OOB;
+#endif
             rb[i].v = __builtin_bit_cast(typename Elem<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ox, 0, 0));
             // advance this row's cursor to the next chunk
             row_p[i] += WG_PIX;
@@ -738,7 +745,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
         const bool more = pc + WG_PIX < p_end;
         if (more) issue_loads();
         const char* sA = smem + cur * 2 * TILE_BYTES;
+#ifndef ABL_W_NO_MMA
         wgrad_mma<T>(sA, sA + TILE_BYTES, wave_m, wave_n, lane, acc);
+#endif
         if (more) write_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -756,7 +765,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
             for (int e = 0; e < 16; ++e) {
                 const int co = co_base + wave_m * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (co >= P.Co) continue;
+#ifndef ABL_W_NO_ATOMIC
                 atomicAdd(P.dw + ((long long)co * RS + tap) * P.Ci + ci, acc[i][j][e]);
+#else
+                if (acc[i][j][e] == 12345.678f) P.dw[0] = 1.f;  // keeps the accumulators alive
+#endif
             }
         }
 }

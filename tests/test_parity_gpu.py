@@ -396,3 +396,68 @@ def test_validation_and_checkpoint_roundtrip(tmp_path, golden_dir):
     k0 = "model.xception_features.block7.rep.1.pointwise.weight"
     assert not torch.equal(sd1[k0], sd3[k0])        # tr took one more step than the checkpoint
     assert torch.equal(torch.load(ck)["generator"][k0].to(DEV), sd3[k0])
+
+
+def _ddp_worker(rank, world, port, q, ddp):
+    """One data-parallel rank.  Both ranks share GPU 0 (rehearsal: RCCL refuses duplicate devices, so the
+    collective backend is gloo); everything else -- flat-arena broadcast, gradient all-reduce on its own
+    stream, weight-gradient stream join, Adam dividing by the world size -- is the multi-GPU code path."""
+    import torch.distributed as dist
+    from bias_gan_amd.comm.distributed import comm as distcomm
+    if ddp:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK="0", BGAMD_DIST_BACKEND="gloo")
+    c, h, w, n = 4, 64, 64, 2
+    cm = distcomm(mode="torchrun" if ddp else "dummy")
+    # different initial weights per rank: the broadcast from rank 0 must make them equal
+    G, _ = build_generator(c, 11 + rank, F32)
+    D, _ = build_discriminator(c, h, w, 21 + rank, F32)
+    G.train(), D.train()
+    g_opt = ph.get_optimizer(G.parameters(), "Adam", 1e-3, 1e-8, 1e-5)
+    d_opt = ph.get_optimizer(D.parameters(), "Adam", 1e-3, 1e-8, 1e-5)
+    crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+    tr = GANTrainer(cm.DistributedModel(G), cm.DistributedModel(D), g_opt, d_opt, crit, losses.L1Loss())
+    labels = crit.draw_labels()
+    for step in range(2):
+        x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 3000 + 10 * step + rank))   # rank-local data
+        d_loss, g_loss = tr.step(x, y, labels=labels)
+    torch.cuda.synchronize()
+    out = {}
+    for name, net in (("G", G), ("D", D)):
+        m = net.arena().master.double()
+        out[name] = (m.sum().item(), m.abs().sum().item(), m[:5].tolist())
+    out["loss"] = (float(d_loss), float(g_loss), cm.metric_average(d_loss, "d", device=torch.device(DEV)))
+    q.put((rank, out))
+    if ddp:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_share_one_gpu():
+    """N > 1 path with real kernels: two ranks (different initial weights, different data) end two full
+    steps with IDENTICAL parameters, which differ from what rank 0 computes alone."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for name in ("G", "D"):
+        assert res[0][name] == res[1][name], f"{name}: parameters differ between the ranks"
+    # metric_average returns the SUM over ranks (comm/distributed.py:15-17)
+    assert abs(res[0]["loss"][2] - (res[0]["loss"][0] + res[1]["loss"][0])) <= 1e-5 * abs(res[0]["loss"][2])
+    solo = ctx.Process(target=_ddp_worker, args=(0, 1, port, q, False))
+    solo.start()
+    _, alone = q.get(timeout=300)
+    solo.join(timeout=120)
+    assert solo.exitcode == 0
+    assert alone["G"] != res[0]["G"] and alone["D"] != res[0]["D"]
