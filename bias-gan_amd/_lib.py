@@ -60,7 +60,7 @@ _SIGS = {
     "bg_norm_eval_affine": [c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp],
     "bg_norm_act_fwd": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
     "bg_norm_act_fwd_stats": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
-                              c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp],
+                              c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
     "bg_norm_act_bwd_apply_stats": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                     c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
     "bg_norm_act_bwd_reduce": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
@@ -172,7 +172,7 @@ def _alg_bytes(name, a) -> float:
     if name == "bg_norm_act_fwd":
         return float(a[9]) * a[10] * _es(a[0]) * (2 + nn(5))
     if name == "bg_norm_act_fwd_stats":
-        return float(a[17]) * a[18] * _es(a[0]) * (2 + nn(13))   # (trailing stat_copies does not shift these)
+        return float(a[17]) * a[18] * _es(a[0]) * (2 + nn(13))
     if name == "bg_norm_act_bwd_reduce":
         return float(a[11]) * a[12] * _es(a[0]) * nn(1, 3, 5)
     if name == "bg_norm_act_bwd_apply":

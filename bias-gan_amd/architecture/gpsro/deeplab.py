@@ -131,7 +131,6 @@ def _norm_kind(m: nn.Module) -> str:
 
 import os as _os
 _FUSED_STATS = _os.environ.get("BGAMD_NO_FUSED_STATS") is None  # A/B switch
-_STAT_COPIES = int(_os.environ.get("BGAMD_STAT_COPIES", "1"))     # accumulator copies the conv tiles spread over (measured: 1 is fastest)
 
 
 def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
@@ -141,8 +140,18 @@ def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
     dense = conv.pointwise if isinstance(conv, SeparableConv2d_same) else conv
     stats = None
     if isinstance(m, nn.BatchNorm2d) and m.training and dense.bias is None and _FUSED_STATS:
-        kp = owner.arena().by_param[id(dense.weight)].phys_shape[0]
-        stats = StatsPool.get(x.device).take(2, _STAT_COPIES, kp)
+        groups = ops.current_bn_groups()
+        n, h, w, _ = x.shape
+        if isinstance(conv, SeparableConv2d_same):
+            s = conv.conv1.stride[0]
+            ho, wo = -(-h // s), -(-w // s)
+        else:
+            k, s, p, d = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+            ho, wo = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
+        # the epilogue attributes whole 128-pixel tiles to a statistic group
+        if groups == 1 or (n % groups == 0 and (n // groups * ho * wo) % 128 == 0):
+            kp = owner.arena().by_param[id(dense.weight)].phys_shape[0]
+            stats = StatsPool.get(x.device).take(2, groups, kp)
     y = conv(x, stats) if stats is not None else conv(x)
     return apply_norm(owner, m, y, res=res, act=act, stats=stats)
 
@@ -159,13 +168,14 @@ def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False, stats=None
                                    float(m.eps), 0.0)
     a = owner.arena()
     gs, bs = a.by_param[id(m.weight)], a.by_param[id(m.bias)]
+    groups = ops.current_bn_groups() if m.training else 1
     if m.training:
         # counted on the host and folded into the buffer when state_dict() is taken
         # (74 one-element device increments per forward would only cost launches)
-        m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + 1
+        m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + groups
     mom = 0.1 if m.momentum is None else float(m.momentum)
     return ops.NormActFn.apply(x, res, m.weight, m.bias, a, gs, bs, m.running_mean, m.running_var, "batch", m.training,
-                               act, float(m.eps), mom, stats)
+                               act, float(m.eps), mom, stats, groups)
 
 
 def fixed_padding_extents(kernel_size, rate):

@@ -47,7 +47,7 @@ struct GemmConvParams {
     int tiles_c, tiles_p;
     double* stat_sum;  // optional per-output-channel sum / sum of squares of the STORED outputs
     double* stat_sq;   // (BatchNorm statistics fused into the epilogue); NULL = off
-    int stat_copies;   // accumulator copies [copies][NO] (power of two): blocks spread over them by id
+    int stat_tiles_per_group;  // pixel tiles per statistic group (sum/sumsq are [groups][NO]); 0 = one group
     int CKp;       // K stride of one tap inside the (zero-padded) weight copy
     int in_bytes;  // exact extent of the activation operand (buffer-load range check)
     int w_bytes;
@@ -191,9 +191,10 @@ __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&a
         __syncthreads();
         const int t = threadIdx.x;
         if (t < TCH && c_base + t < P.NO) {
-            // every pixel tile adds into the same NO addresses; same-address atomics serialise at the
-            // memory side, so the blocks are spread over `copies` accumulators (summed by the consumer)
-            const long long o = (long long)(blockIdx.x & (P.stat_copies - 1)) * P.NO + c_base + t;
+            // statistic groups are contiguous pixel ranges (sub-batches normalised separately); a tile
+            // never straddles two (checked on the host)
+            const int grp = P.stat_tiles_per_group ? (int)(p_base / TILE) / P.stat_tiles_per_group : 0;
+            const long long o = (long long)grp * P.NO + c_base + t;
             atomicAdd(P.stat_sum + o, (double)(red[t * 2] + red[(TCH + t) * 2]));
             atomicAdd(P.stat_sq + o, (double)(red[t * 2 + 1] + red[(TCH + t) * 2 + 1]));
         }
@@ -912,12 +913,14 @@ extern "C" int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w
 }
 
 extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum,
-                                   double* sumsq, int32_t copies, void* stream) {
+                                   double* sumsq, int32_t groups, void* stream) {
     int rc = check_conv_desc(d, "bg_conv2d_fwd_stats");
     if (rc) return rc;
     BG_CHECK_ARG(x && w && y && sum && sumsq && aligned16(x) && aligned16(w) && aligned16(y),
                  "bg_conv2d_fwd_stats: null/unaligned pointer");
-    BG_CHECK_ARG(copies >= 1 && copies <= 64 && (copies & (copies - 1)) == 0, "bg_conv2d_fwd_stats: copies must be a power of two <= 64");
+    const long long M_ = (long long)d->N * d->Ho * d->Wo;
+    BG_CHECK_ARG(groups >= 1 && M_ % groups == 0 && (groups == 1 || (M_ / groups) % TILE == 0),
+                 "bg_conv2d_fwd_stats: the pixels of a statistic group must be a multiple of %d (or groups == 1)", TILE);
     GemmConvParams P{};
     P.in = x; P.w = w; P.out = y; P.bias = nullptr;
     P.N = d->N; P.IH = d->H; P.IW = d->W; P.OH = d->Ho; P.OW = d->Wo;
@@ -925,7 +928,8 @@ extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const v
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
     P.transposed = 0;
     P.M = (long long)d->N * d->Ho * d->Wo;
-    P.stat_sum = sum; P.stat_sq = sumsq; P.stat_copies = copies;
+    P.stat_sum = sum; P.stat_sq = sumsq;
+    P.stat_tiles_per_group = groups > 1 ? (int)(M_ / groups / TILE) : 0;
     if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
     return launch_gemm_conv<float>(P, (hipStream_t)stream);
 }

@@ -282,7 +282,6 @@ struct EwParams {
     float* rmean; float* rvar;      // running statistics (batch norm, groups == 1) or NULL
     float* mean_out; float* rstd_out;
     int gx, gy;
-    int stat_copies;  // sum/sumsq are [copies][groups*C] partial accumulators (conv epilogue), 1 = plain
 };
 
 template <typename T>
@@ -310,13 +309,8 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const long long i = (long long)g * P.C + c + e;
-            double su = P.sum[i], sq = P.sumsq[i];
-            for (int k = 1; k < P.stat_copies; ++k) {
-                su += P.sum[(long long)k * gridDim.z * P.C + i];
-                sq += P.sumsq[(long long)k * gridDim.z * P.C + i];
-            }
-            const double m = su * inv_n;
-            double var = sq * inv_n - m * m;  // the cancellation-prone step stays in fp64
+            const double m = P.sum[i] * inv_n;
+            double var = P.sumsq[i] * inv_n - m * m;  // the cancellation-prone step stays in fp64
             if (var < 0.0 || P.rows_per_group == 1) var = 0.0;
             const float r = rsqrtf((float)var + P.eps);
             const float gm = P.gamma ? P.gamma[c + e] : 1.f;
@@ -325,10 +319,21 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
             if (publish) {
                 P.mean_out[i] = (float)m;
                 P.rstd_out[i] = r;
-                if (P.rmean) {
-                    const double unb = P.rows_per_group > 1 ? var * n / (n - 1.0) : var;
-                    P.rmean[c + e] = (1.f - P.momentum) * P.rmean[c + e] + P.momentum * (float)m;
-                    P.rvar[c + e] = (1.f - P.momentum) * P.rvar[c + e] + P.momentum * (float)unb;
+                if (P.rmean && g == 0) {
+                    // BatchNorm over several statistic groups (sub-batches the reference pushes through the
+                    // layer in separate calls): one momentum update per group, in group order
+                    float rm = P.rmean[c + e], rv = P.rvar[c + e];
+                    for (int gg = 0; gg < (int)gridDim.z; ++gg) {
+                        const long long j = (long long)gg * P.C + c + e;
+                        const double mg = P.sum[j] * inv_n;
+                        double vg = P.sumsq[j] * inv_n - mg * mg;
+                        if (vg < 0.0 || P.rows_per_group == 1) vg = 0.0;
+                        const double unb = P.rows_per_group > 1 ? vg * n / (n - 1.0) : vg;
+                        rm = (1.f - P.momentum) * rm + P.momentum * (float)mg;
+                        rv = (1.f - P.momentum) * rv + P.momentum * (float)unb;
+                    }
+                    P.rmean[c + e] = rm;
+                    P.rvar[c + e] = rv;
                 }
             }
         }
@@ -637,16 +642,15 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
                                      const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, float* mean, float* rstd, const void* res,
                                      int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
-                                     int32_t act, int32_t stat_copies, void* stream) {
+                                     int32_t act, void* stream) {
     int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_fwd_stats");
-    BG_CHECK_ARG(stat_copies >= 1 && stat_copies <= 64, "bg_norm_act_fwd_stats: bad stat_copies");
     if (rc) return rc;
     CHECK_LD(ldx, "bg_norm_act_fwd_stats");
     CHECK_LD(ldy, "bg_norm_act_fwd_stats");
     BG_CHECK_ARG(x && y && sum && sumsq && mean && rstd && aligned16(x) && aligned16(y),
                  "bg_norm_act_fwd_stats: null/unaligned pointer");
-    BG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && !(running_mean && groups != 1),
-                 "bg_norm_act_fwd_stats: running statistics need batch statistics (groups == 1), both or none");
+    BG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
+                 "bg_norm_act_fwd_stats: running statistics come in pairs");
     if (res) {
         BG_CHECK_ARG(aligned16(res), "bg_norm_act_fwd_stats: unaligned res");
         CHECK_LD(ldres, "bg_norm_act_fwd_stats");
@@ -658,7 +662,7 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd_stats: too many groups");
     EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
                sum, sumsq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd};
-    P.gx = t.gx; P.gy = t.gy; P.stat_copies = stat_copies;
+    P.gx = t.gx; P.gy = t.gy;
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
                                                    (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("norm_act_fwd_kernel(stats)");

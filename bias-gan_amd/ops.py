@@ -208,7 +208,7 @@ class Conv2dFn(torch.autograd.Function):
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
         if stats is not None:
-            # stats: fp64 [2, copies, kp] (copies a power of two): the tiles spread their atomics over the copies
+            # stats: fp64 [2, groups, kp]; groups = sub-batches with separate BatchNorm statistics
             assert bslot is None and stats.dim() == 3 and stats.shape[0] == 2 and stats.shape[2] == kp
             assert stats.dtype == torch.float64
             L.call("bg_conv2d_fwd_stats", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr(), stats[0].data_ptr(),
@@ -355,6 +355,32 @@ class DwConv3x3Fn(torch.autograd.Function):
 
 
 # ------------------------------------------------------- norm + residual + LeakyReLU
+_BN_GROUPS = [1]
+
+
+class batch_groups:
+    """Context: BatchNorm layers (training mode) take their statistics separately over `groups` equal
+    sub-batches of the batch they see, and apply one running-statistics update per sub-batch, in order --
+    exactly what the reference computes when it pushes those sub-batches through the network in separate
+    calls (D(real) then D(fake), train_gan.py:253-254), but in one pass over twice the rows."""
+
+    def __init__(self, groups: int):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        _BN_GROUPS.append(self.groups)
+        return self
+
+    def __exit__(self, *exc):
+        _BN_GROUPS.pop()
+        return False
+
+
+def current_bn_groups() -> int:
+    return _BN_GROUPS[-1]
+
+
+
 class NormActFn(torch.autograd.Function):
     """y = act( norm(x) + res ).
 
@@ -365,8 +391,9 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum,
-                pre_stats=None):
-        """pre_stats: fp64 [2, copies, C] partial sums already produced by the convolution's epilogue
+                pre_stats=None, bn_groups=1):
+        """bn_groups: 'batch' statistics are taken separately over that many equal sub-batches (see
+        batch_groups()).  pre_stats: fp64 [2, groups, C] sums already produced by the convolution's epilogue
         (bg_conv2d_fwd_stats); skips the separate statistics pass."""
         x = nhwc(x)
         n, h, w, c = x.shape
@@ -375,15 +402,15 @@ class NormActFn(torch.autograd.Function):
         if res is not None:
             res = nhwc(res)
         use_batch_stats = (kind == "batch" and training) or kind == "instance"
-        groups = n if kind == "instance" else 1
+        groups = n if kind == "instance" else (bn_groups if kind == "batch" and training else 1)
+        assert n % groups == 0, f"batch of {n} does not split into {groups} statistic groups"
         mean = rstd = scale = shift = None
         y = new_act(n, h, w, c, x.dtype, dev)
         gptr = None if gslot is None else arena.master_ptr(gslot)
         bptr = None if bslot is None else arena.master_ptr(bslot)
         if kind != "identity" and use_batch_stats:
-            copies = 1
-            if pre_stats is not None and groups == 1:
-                s, copies = pre_stats, pre_stats.shape[1]      # [2, copies, C] partial accumulators
+            if pre_stats is not None and pre_stats.shape[1] == groups:
+                s = pre_stats
             else:
                 s = _f64(2, groups, c, device=dev)
                 L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
@@ -392,8 +419,7 @@ class NormActFn(torch.autograd.Function):
             # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
             L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
                    momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act),
-                   copies)
+                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
         else:
             if kind != "identity":  # BatchNorm in eval mode: affine from the running statistics
                 mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
@@ -421,12 +447,12 @@ class NormActFn(torch.autograd.Function):
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
         if kind == "identity":
             if dx is None and dres is None:
-                return (None,) * 15
+                return (None,) * 16
             # dx and dres are the same tensor values: write once, alias
             out = dx if dx is not None else dres
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None,
                    out.data_ptr(), ld_of(out), None, 0, rows, c, groups, act)
-            return (out if need_dx else None, out if need_res else None) + (None,) * 13
+            return (out if need_dx else None, out if need_res else None) + (None,) * 14
         want_affine_grads = gslot is not None and gslot.param.requires_grad
         gptr = None if gslot is None else arena.master_ptr(gslot)
         bptr = None if bslot is None else arena.master_ptr(bslot)
@@ -450,7 +476,7 @@ class NormActFn(torch.autograd.Function):
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
-        return (dx, dres) + (None,) * 13
+        return (dx, dres) + (None,) * 14
 
 
 def leaky_relu(x):

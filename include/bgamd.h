@@ -77,10 +77,11 @@ int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w, const flo
 /* Same as bg_conv2d_fwd without bias, and additionally sum[.][c] += sum_pixels y, sumsq[.][c] += sum_pixels y^2
  * of the outputs as stored (fp64, caller zeroes): the batch statistics of the BatchNorm that follows
  * the convolution, taken from the accumulators instead of re-reading y (replaces bg_norm_stats).
- * sum/sumsq are [copies][Cout] (copies a power of two): workgroups spread their atomics over the copies
- * (same-address atomics serialise); the statistic is the sum over copies. */
+ * groups > 1: the output pixels form `groups` equal contiguous ranges (sub-batches that are normalised
+ * separately, e.g. D(real) and D(fake) pushed through the network as one batch); sum/sumsq are
+ * [groups][Cout].  A group's pixel count must then be a multiple of 128. */
 int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum, double* sumsq,
-                        int32_t copies, void* stream);
+                        int32_t groups, void* stream);
 /* dx = conv_transpose(dy, w).  wt: K-padded CRSK copy of the weights.  Overwrites dx. */
 int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
 /* dw += x (*) dy, dw fp32 KRSC (accumulated with float atomics; caller zeroes it
@@ -139,15 +140,15 @@ int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const 
 int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
                     const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
                     int32_t act, void* stream);
-/* (stat_copies: sum/sumsq hold that many partial accumulators [copies][groups*C], see bg_conv2d_fwd_stats.)
- * bg_norm_finalize + bg_norm_act_fwd in ONE launch (training-mode statistics): every thread derives
+/* bg_norm_finalize + bg_norm_act_fwd in ONE launch (training-mode statistics): every thread derives
  * the affine of its channels from the fp64 sums; the first row-block of each group also writes
- * mean/rstd (fp32 [groups,C]) and applies the running-statistics update. */
+ * mean/rstd (fp32 [groups,C]).  running_* (BatchNorm) get one momentum update per group, in group
+ * order, from group 0's first row-block: groups > 1 with running statistics is BatchNorm over
+ * sub-batches that the reference pushes through the layer in separate calls. */
 int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, const double* sum, const double* sumsq,
                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* rstd, const void* res, int32_t ldres, void* y,
-                          int32_t ldy, int64_t rows, int32_t C, int32_t groups, int32_t act, int32_t stat_copies,
-                          void* stream);
+                          int32_t ldy, int64_t rows, int32_t C, int32_t groups, int32_t act, void* stream);
 /* Backward pass 1: g = dy * act'(y);  s1[g,c] += sum g, s2[g,c] += sum g*xhat
  * (fp64, caller zeroes) with xhat = (x-mean)*rstd.  y == NULL with act != 0 (layers WITHOUT a
  * residual): the LeakyReLU branch is taken from the recomputed pre-activation

@@ -56,7 +56,7 @@ def main():
             i = nxt()
             L.call("bg_norm_act_fwd_stats", dt, xs[i].data_ptr(), cp, s.data_ptr(), ss.data_ptr(), gamma.data_ptr(),
                    beta.data_ptr(), 1e-5, 0.1, None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, ys[i].data_ptr(), cp,
-                   rows, cp, 1, 1, 1)
+                   rows, cp, 1, 1)
 
         def stats():
             i = nxt()

