@@ -45,6 +45,12 @@ class GANTrainer:
         # D(real) and D(fake) of the D-step as ONE pass over the concatenated batch with per-half BatchNorm
         # statistics (ops.batch_groups): same results, kernels twice as large (BGAMD_NO_BATCHED_D=1 disables)
         self._batched_d = not os.environ.get("BGAMD_NO_BATCHED_D")
+        # the G-step's generator forward reads nothing the D-step writes: it is issued on the side stream as
+        # soon as the D-step's own (graph-free) generator forward is enqueued and runs under D's forward and
+        # backward.  Only without host-drawn noise (the reference's RNG draw order is noise, labels, noise).
+        self._g_ahead_ok = not os.environ.get("BGAMD_NO_G_PREFETCH")
+        self._g_ahead = None
+        self._want_g_ahead = False
         self._d_params = [p for p in _unwrap(discriminator).parameters()]
 
     # -- train_gan.py:250-271 -------------------------------------------------------------
@@ -53,6 +59,13 @@ class GANTrainer:
             with torch.no_grad():                   # no graph through G: D's update cannot use it
                 outputs_fake = self.generator(inputs)
             n = outputs_real.shape[0]
+            if self._want_g_ahead:
+                if self._side == "auto":
+                    self._side = torch.cuda.Stream(device=inputs.device)
+                if self._side is not None:
+                    self._side.wait_stream(torch.cuda.current_stream(inputs.device))
+                    with torch.cuda.stream(self._side):
+                        self._g_ahead = (inputs, self.generator(inputs))
             with ops.batch_groups(2):               # group 0 = real, group 1 = fake: the reference's call order
                 logits, _ = self.discriminator(torch.cat((outputs_real, outputs_fake), dim=0))
             return self._d_update(logits[:n], logits[n:], outputs_fake, outputs_real, labels, eta)
@@ -99,7 +112,14 @@ class GANTrainer:
         for p in self._d_params:                    # D is only differentiated w.r.t. its input here
             p.requires_grad_(False)
         try:
-            outputs_fake = self.generator(inputs)
+            ahead, self._g_ahead = self._g_ahead, None
+            if ahead is not None and ahead[0] is inputs:
+                outputs_fake = ahead[1]
+                main = torch.cuda.current_stream(inputs.device)
+                main.wait_stream(self._side)
+                outputs_fake.record_stream(main)
+            else:
+                outputs_fake = self.generator(inputs)
             # D's Adam update (and its gradient all-reduce) must land before D is used again
             self._finish_d()
             logits_fake, _ = self.discriminator(outputs_fake)
@@ -135,8 +155,12 @@ class GANTrainer:
         train_generator = (s < self.warmup) or (s % self.freq_g == 0)            # train_gan.py:247
         train_discriminator = (s >= self.warmup) and (s % self.freq_d == 0)      # train_gan.py:248
         d_loss = g_loss = None
+        g = _unwrap(self.generator)
+        self._want_g_ahead = (self._g_ahead_ok and train_discriminator and train_generator and inputs.is_cuda
+                              and (getattr(g, "noise_dimensions", 0) == 0 or getattr(g, "noise_on_device", False)))
         if train_discriminator:
             d_loss = self.d_step(inputs, outputs_real, labels, eta)
+        self._want_g_ahead = False
         if train_generator:
             g_loss = self.g_step(inputs, outputs_real, masks)
         self._finish_d()
