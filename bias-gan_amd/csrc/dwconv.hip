@@ -15,6 +15,7 @@ struct DwParams {
     int items;  // Wo*(C/VEC) (fwd) or W*(C/VEC) (bwd_data): work items of one image row
     int bx;     // 256-thread blocks per image row; the grid is 1-D: rows * bx blocks
     int rb, bands;  // dw_s1_kernel: output rows per band, bands per image
+    int wgroups, bands_per_phase;  // ... per column phase / row phase (dilation D: D phases each way)
 };
 
 // 1-D grid -> (image row, block inside the row).  Blocks with the same id % 8 share an
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(256) void dw_fwd_tw_kernel(DwParams P) {
 // row: columns left/right of the image and rows above/below it fall outside the descriptor's range
 // and read as zero, which IS the "same" padding -- no branches around the loads.  The next input
 // row is fetched while the current one is being used.  FLIP = 1 reverses the taps (data gradient).
+// Dilation D (exit flow, D = 2) is the same kernel on the D x D sub-lattices of the image: a thread's
+// four output columns and the rows it walks are D apart, so its window is again 3 rows x 6 columns.
 template <typename T, int FLIP>
 __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
     constexpr int VEC = Elem<T>::VEC;
@@ -150,15 +153,18 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
     if (idx >= (unsigned)P.items) return;
     const unsigned wq = idx / cv;
     const int c = (int)(idx - wq * cv) * VEC;
-    const int wo0 = (int)wq * TW;
+    const int D = P.dil;
+    const int pc = (int)wq / P.wgroups, gi = (int)wq - pc * P.wgroups;  // column phase, group inside it
+    const int wo0 = pc + gi * TW * D;
     const int n = band / P.bands, b = band - n * P.bands;
-    const int ho0 = b * P.rb;
-    const int ho1 = min(ho0 + P.rb, P.Ho);
+    const int pr = b / P.bands_per_phase, bi = b - pr * P.bands_per_phase;  // row phase, band inside it
+    const int ho0 = pr + bi * P.rb * D;
+    const int ho1 = min(ho0 + P.rb * D, P.Ho);
     const unsigned row_bytes = (unsigned)P.W * P.ldx * sizeof(T);
     const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * row_bytes;
     int voff[NCOL];  // negative (left of the image) -> huge unsigned -> out of range -> 0
 #pragma unroll
-    for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 - 1 + j) * P.ldx + c) * (int)sizeof(T);
+    for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 + (j - 1) * D) * P.ldx + c) * (int)sizeof(T);
     Chunk<T> wv[9];
     {
         const T* w = reinterpret_cast<const T*>(P.w) + c;
@@ -173,12 +179,12 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
         for (int j = 0; j < NCOL; ++j) dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
     };
     Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], nx[NCOL];
-    load_row(ho0 - 1, r0);
+    load_row(ho0 - D, r0);
     load_row(ho0, r1);
-    load_row(ho0 + 1, r2);
+    load_row(ho0 + D, r2);
     T* y = reinterpret_cast<T*>(P.y) + (((long long)n * P.Ho + ho0) * P.Wo + wo0) * P.ldy + c;
-    for (int ho = ho0; ho < ho1; ++ho) {
-        if (ho + 1 < ho1) load_row(ho + 2, nx);  // prefetch: consumed in the next iteration
+    for (int ho = ho0; ho < ho1; ho += D) {
+        if (ho + D < ho1) load_row(ho + 2 * D, nx);  // prefetch: consumed in the next iteration
         float acc[TW][VEC];
 #pragma unroll
         for (int t = 0; t < TW; ++t)
@@ -196,14 +202,14 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
                 }
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
-            if (wo0 + t < P.Wo) {
+            if (wo0 + t * D < P.Wo) {
                 Chunk<T> o;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o.set(e, acc[t][e]);
-                o.store(y + (long long)t * P.ldy);
+                o.store(y + (long long)t * D * P.ldy);
             }
         }
-        y += (long long)P.Wo * P.ldy;
+        y += (long long)D * P.Wo * P.ldy;
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) {
             r0[j] = r1[j];
@@ -255,6 +261,84 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwParams P) {
     o.store(reinterpret_cast<T*>(P.y) + (((long long)n * P.H + ih) * P.W + iw) * P.ldx + c);
 }
 
+// Stride-2 data gradient in gather form.  With the "same" padding of SeparableConv2d_same (one pixel
+// in front) dx[2ho + a][2wo + b] only receives
+//   a = 0: tap row 1 of dy row ho;          a = 1: tap row 0 of dy row ho+1 and tap row 2 of dy row ho
+// (same for columns), so a thread that holds dy[ho..ho+1][wo0..wo0+2] of one channel vector writes the
+// 2 x 4 block dx[2ho..2ho+1][2wo0..2wo0+3] and slides down one dy row per step: dy is read once
+// (plus a one-column halo), dx written once, no divisibility tests.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(DwParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int TW = 2;
+    typedef typename Elem<T>::vec_t vec_t;
+    const unsigned cv = P.C / VEC;
+    int band, xblk;
+    dw_block_to_row(P.bx, band, xblk);
+    const unsigned idx = xblk * 256u + threadIdx.x;
+    if (idx >= (unsigned)P.items) return;
+    const unsigned wq = idx / cv;
+    const int c = (int)(idx - wq * cv) * VEC;
+    const int wo0 = (int)wq * TW;
+    const int n = band / P.bands, b = band - n * P.bands;
+    const int ho0 = b * P.rb;
+    const int ho1 = min(ho0 + P.rb, P.Ho);
+    const unsigned grow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
+    const char* gn = reinterpret_cast<const char*>(P.x) + (long long)n * P.Ho * grow_bytes;  // P.x = dy
+    int goff[TW + 1];
+#pragma unroll
+    for (int j = 0; j <= TW; ++j) goff[j] = ((wo0 + j) * P.ldy + c) * (int)sizeof(T);
+    float wf[9][VEC];
+    {
+        const T* w = reinterpret_cast<const T*>(P.w) + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            Chunk<T> wv;
+            wv.load(w + t * P.C);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) wf[t][e] = wv.get(e);
+        }
+    }
+    auto load_row = [&](int ho, Chunk<T>(&dst)[TW + 1]) {
+        const bool ok = (unsigned)ho < (unsigned)P.Ho;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(gn + (long long)(ok ? ho : 0) * grow_bytes), 0, ok ? grow_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j <= TW; ++j) dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[j], 0, 0));
+    };
+    Chunk<T> g0[TW + 1], g1[TW + 1];
+    load_row(ho0, g0);
+    T* dx = reinterpret_cast<T*>(P.y) + (((long long)n * P.H + 2 * ho0) * P.W + 2 * wo0) * P.ldx + c;  // P.y = dx
+    for (int ho = ho0; ho < ho1; ++ho) {
+        load_row(ho + 1, g1);
+        const bool row1 = 2 * ho + 1 < P.H;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            Chunk<T> o00, o01, o10, o11;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float a = g0[t].get(e), bq = g0[t + 1].get(e), cq = g1[t].get(e), dq = g1[t + 1].get(e);
+                o00.set(e, a * wf[4][e]);
+                o01.set(e, fmaf(bq, wf[3][e], a * wf[5][e]));
+                o10.set(e, fmaf(cq, wf[1][e], a * wf[7][e]));
+                o11.set(e, fmaf(dq, wf[0][e], fmaf(cq, wf[2][e], fmaf(bq, wf[6][e], a * wf[8][e]))));
+            }
+            const int iw = 2 * (wo0 + t);
+            if (iw < P.W) {
+                o00.store(dx + (long long)(2 * t) * P.ldx);
+                if (row1) o10.store(dx + ((long long)P.W + 2 * t) * P.ldx);
+            }
+            if (iw + 1 < P.W) {
+                o01.store(dx + (long long)(2 * t + 1) * P.ldx);
+                if (row1) o11.store(dx + ((long long)P.W + 2 * t + 1) * P.ldx);
+            }
+        }
+        dx += 2LL * P.W * P.ldx;
+#pragma unroll
+        for (int j = 0; j <= TW; ++j) g0[j] = g1[j];
+    }
+}
+
 // dw[r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,c] * x[n, ho*st-dil+r*dil, wo*st-dil+s*dil, c]
 // block = TX channel vectors x TY pixel lanes; a block owns a run of output rows,
 // keeps 9*VEC fp32 partials per thread, folds the TY lanes through LDS one tap at a
@@ -268,6 +352,7 @@ struct DwWParams {
     int rows_per_block;
     int tx, log_tx;
     int gx, bands;  // dw_bwd_weight_s1_kernel: channel blocks, row bands per image
+    int wgroups, bands_per_phase;  // ... column groups per column phase, bands per row phase (dilation)
 };
 
 template <typename T, int FAST /* stride 1, dilation 1: sliding 3-column window */>
@@ -394,22 +479,25 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    const int D = P.dil;  // dilation D: the D x D sub-lattices of the image, see dw_s1_kernel
     const int n = band / P.bands, b = band - n * P.bands;
-    const int ho0 = b * P.rows_per_block;
-    const int ho1 = min(ho0 + P.rows_per_block, P.Ho);
+    const int pr = b / P.bands_per_phase, bi = b - pr * P.bands_per_phase;
+    const int ho0 = pr + bi * P.rows_per_block * D;
+    const int ho1 = min(ho0 + P.rows_per_block * D, P.Ho);
     const unsigned xrow_bytes = (unsigned)P.W * P.ldx * sizeof(T);
     const unsigned grow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
     const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * xrow_bytes;
     const char* gn = reinterpret_cast<const char*>(P.dy) + (long long)n * P.Ho * grow_bytes;
-    const int nwq = (P.Wo + TW - 1) / TW;
+    const int nwq = D * P.wgroups;
     if (c_ok) {
         for (int wq = ly; wq < nwq; wq += ty) {
-            const int wo0 = wq * TW;
+            const int pc = wq / P.wgroups, gi = wq - pc * P.wgroups;
+            const int wo0 = pc + gi * TW * D;
             int voff[NCOL], goff[TW];
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 - 1 + j) * P.ldx + c) * (int)sizeof(T);
+            for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 + (j - 1) * D) * P.ldx + c) * (int)sizeof(T);
 #pragma unroll
-            for (int t = 0; t < TW; ++t) goff[t] = ((wo0 + t) * P.ldy + c) * (int)sizeof(T);
+            for (int t = 0; t < TW; ++t) goff[t] = ((wo0 + t * D) * P.ldy + c) * (int)sizeof(T);
             auto load_row = [&](int ih, Chunk<T>(&dst)[NCOL]) {
                 const bool ok = (unsigned)ih < (unsigned)P.H;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -419,16 +507,16 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
                     dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
             };
             Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], nx[NCOL], gv[TW];
-            load_row(ho0 - 1, r0);
+            load_row(ho0 - D, r0);
             load_row(ho0, r1);
-            load_row(ho0 + 1, r2);
-            for (int ho = ho0; ho < ho1; ++ho) {
+            load_row(ho0 + D, r2);
+            for (int ho = ho0; ho < ho1; ho += D) {
                 const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<char*>(gn + (long long)ho * grow_bytes), 0, grow_bytes, 0x00020000);
 #pragma unroll
                 for (int t = 0; t < TW; ++t)  // columns past Wo are out of range: zero gradient
                     gv[t].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rg, goff[t], 0, 0));
-                if (ho + 1 < ho1) load_row(ho + 2, nx);
+                if (ho + D < ho1) load_row(ho + 2 * D, nx);
 #pragma unroll
                 for (int t = 0; t < TW; ++t)
 #pragma unroll
@@ -446,6 +534,94 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
                     r1[j] = r2[j];
                     r2[j] = nx[j];
                 }
+            }
+        }
+    }
+    const int row_w = P.tx * VEC;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[ly * row_w + lx * VEC + e] = acc[t][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < row_w; i += 256) {
+            float a = 0.f;
+            for (int y = 0; y < ty; ++y) a += red[y * row_w + i];
+            const int ch = bx * row_w + i;
+            if (ch < P.C) atomicAdd(P.dw + (long long)t * P.C + ch, a);
+        }
+    }
+}
+
+// Stride-2 weight gradient: a thread owns TW = 2 output columns of one channel vector (input columns
+// 2*wo0-1 .. 2*wo0+3) and walks the output rows of a band; input row 2*ho+1 is shared by output rows ho
+// and ho+1, so every step loads two new input rows -- each x element is read once along rows, 1.25 times
+// along columns (the generic path reads it up to 2.25 times through nine predicated loads per output).
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_weight_s2_kernel(DwWParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int TW = 2, NCOL = 2 * TW + 1;
+    typedef typename Elem<T>::vec_t vec_t;
+    __shared__ float red[256 * VEC];
+    const int lx = threadIdx.x & (P.tx - 1);
+    const int ly = threadIdx.x >> P.log_tx;
+    const int ty = 256 >> P.log_tx;
+    int band, bx;
+    dw_block_to_row(P.gx, band, bx);
+    const int c = (bx * P.tx + lx) * VEC;
+    const bool c_ok = c < P.C;
+    float acc[9][VEC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    const int n = band / P.bands, b = band - n * P.bands;
+    const int ho0 = b * P.rows_per_block;
+    const int ho1 = min(ho0 + P.rows_per_block, P.Ho);
+    const unsigned xrow_bytes = (unsigned)P.W * P.ldx * sizeof(T);
+    const unsigned grow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
+    const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * xrow_bytes;
+    const char* gn = reinterpret_cast<const char*>(P.dy) + (long long)n * P.Ho * grow_bytes;
+    const int nwq = (P.Wo + TW - 1) / TW;
+    if (c_ok) {
+        for (int wq = ly; wq < nwq; wq += ty) {
+            const int wo0 = wq * TW;
+            int voff[NCOL], goff[TW];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) voff[j] = ((2 * wo0 - 1 + j) * P.ldx + c) * (int)sizeof(T);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) goff[t] = ((wo0 + t) * P.ldy + c) * (int)sizeof(T);
+            auto load_row = [&](int ih, Chunk<T>(&dst)[NCOL]) {
+                const bool ok = (unsigned)ih < (unsigned)P.H;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(xn + (long long)(ok ? ih : 0) * xrow_bytes), 0, ok ? xrow_bytes : 0u, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j)
+                    dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
+            };
+            Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], gv[TW];
+            load_row(2 * ho0 - 1, r0);
+            for (int ho = ho0; ho < ho1; ++ho) {
+                const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(gn + (long long)ho * grow_bytes), 0, grow_bytes, 0x00020000);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)  // columns past Wo are out of range: zero gradient
+                    gv[t].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rg, goff[t], 0, 0));
+                load_row(2 * ho, r1);
+                load_row(2 * ho + 1, r2);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float g = gv[t].get(e);
+                            acc[0 + s][e] = fmaf(g, r0[2 * t + s].get(e), acc[0 + s][e]);
+                            acc[3 + s][e] = fmaf(g, r1[2 * t + s].get(e), acc[3 + s][e]);
+                            acc[6 + s][e] = fmaf(g, r2[2 * t + s].get(e), acc[6 + s][e]);
+                        }
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) r0[j] = r2[j];
             }
         }
     }
@@ -483,9 +659,13 @@ int launch_dw_s1(int dtype, DwParams P, int flip, hipStream_t st, const char* wh
     static const int k_rb = getenv("BGAMD_DW_RB") ? atoi(getenv("BGAMD_DW_RB")) : 4;  // tuning knob
     const int cv = P.C / dtype_vec(dtype);
     BG_CHECK_ARG((long long)P.W * P.ldx * 4 < 0x7fffffffLL, "%s: image row too large", who);
-    P.rb = k_rb < P.Ho ? k_rb : P.Ho;
-    P.bands = (P.Ho + P.rb - 1) / P.rb;
-    P.items = ((P.Wo + 3) / 4) * cv;
+    const int D = P.dil;
+    const int vrows = (P.Ho + D - 1) / D, vcols = (P.Wo + D - 1) / D;  // rows / columns of one sub-lattice
+    P.rb = k_rb < vrows ? k_rb : vrows;
+    P.bands_per_phase = (vrows + P.rb - 1) / P.rb;
+    P.bands = D * P.bands_per_phase;
+    P.wgroups = (vcols + 3) / 4;
+    P.items = D * P.wgroups * cv;
     P.bx = (P.items + 255) / 256;
     const long long blocks = (long long)P.N * P.bands * P.bx;
     BG_CHECK_ARG(blocks <= 0x7fffffffLL, "%s: grid too large", who);
@@ -507,7 +687,8 @@ extern "C" int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const vo
     const int cv = d->C / dtype_vec(d->dtype);
     const int sd = d->stride * 10 + d->dil;
     static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
-    if (sd == 11 && !old11) return launch_dw_s1(d->dtype, P, 0, st, "dw_s1_kernel");
+    static const bool old_sd = getenv("BGAMD_DW_SD_OLD") != nullptr;  // A/B switch: stride-2 / dilation-2 on the generic kernels
+    if ((sd == 11 || (sd == 12 && !old_sd)) && !old11) return launch_dw_s1(d->dtype, P, 0, st, "dw_s1_kernel");
     if (sd == 11 || sd == 12 || sd == 21) {
         P.items = ((d->Wo + 3) / 4) * cv;
         P.bx = (P.items + 255) / 256;
@@ -541,7 +722,8 @@ extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, co
         // (dy plays the input, dx the output; both are H x W)
         DwParams Q{dy, w, dx, d->N, d->H, d->W, d->C, d->H, d->W, 1, d->dil, d->ldy, d->ldx, 0, 0};
         static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
-        if (d->dil == 1 && !old11) return launch_dw_s1(d->dtype, Q, 1, st, "dw_s1_kernel(flip)");
+        static const bool old_sd = getenv("BGAMD_DW_SD_OLD") != nullptr;
+        if (!old11 && (d->dil == 1 || !old_sd)) return launch_dw_s1(d->dtype, Q, 1, st, "dw_s1_kernel(flip)");
         Q.items = ((d->W + 3) / 4) * cv;
         Q.bx = (Q.items + 255) / 256;
         BG_CHECK_ARG(rows * Q.bx <= 0x7fffffffLL, "bg_dwconv3x3_bwd_data: grid too large");
@@ -549,6 +731,19 @@ extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, co
         if (d->dil == 1) BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 1, 1>), grid, dim3(256), 0, st, Q));
         else BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_fwd_tw_kernel<T, 1, 2, 1>), grid, dim3(256), 0, st, Q));
         BG_CHECK_LAUNCH("dw_fwd_tw_kernel(flip)");
+        return BG_OK;
+    }
+    static const bool old_s2 = getenv("BGAMD_DW_OLD") != nullptr || getenv("BGAMD_DW_SD_OLD") != nullptr;  // A/B switch
+    if (d->stride == 2 && d->dil == 1 && !old_s2) {
+        BG_CHECK_ARG((long long)d->Wo * d->ldy * 4 < 0x7fffffffLL, "bg_dwconv3x3_bwd_data: image row too large");
+        P.rb = 4 < d->Ho ? 4 : d->Ho;
+        P.bands = (d->Ho + P.rb - 1) / P.rb;
+        P.items = ((d->Wo + 1) / 2) * cv;
+        P.bx = (P.items + 255) / 256;
+        const long long blocks = (long long)d->N * P.bands * P.bx;
+        BG_CHECK_ARG(blocks <= 0x7fffffffLL, "bg_dwconv3x3_bwd_data: grid too large");
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw_bwd_data_s2_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+        BG_CHECK_LAUNCH("dw_bwd_data_s2_kernel");
         return BG_OK;
     }
     P.items = d->W * cv;
@@ -577,18 +772,36 @@ extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, c
     const int gx = (cv + best - 1) / best;
     hipStream_t st = (hipStream_t)stream;
     static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
-    if (d->stride == 1 && d->dil == 1 && !old11) {
+    static const bool old_sd = getenv("BGAMD_DW_SD_OLD") != nullptr;
+    if (d->stride == 1 && (d->dil == 1 || (d->dil == 2 && !old_sd)) && !old11) {
         static const int k_rb = getenv("BGAMD_DWW_RB") ? atoi(getenv("BGAMD_DWW_RB")) : 4;  // tuning knob
         BG_CHECK_ARG((long long)d->W * d->ldx * 4 < 0x7fffffffLL && (long long)d->Wo * d->ldy * 4 < 0x7fffffffLL,
                      "bg_dwconv3x3_bwd_weight: image row too large");
-        P.rows_per_block = k_rb < d->Ho ? k_rb : d->Ho;
-        P.bands = (d->Ho + P.rows_per_block - 1) / P.rows_per_block;
+        const int D = d->dil;
+        const int vrows = (d->Ho + D - 1) / D, vcols = (d->Wo + D - 1) / D;
+        P.rows_per_block = k_rb < vrows ? k_rb : vrows;
+        P.bands_per_phase = (vrows + P.rows_per_block - 1) / P.rows_per_block;
+        P.bands = D * P.bands_per_phase;
+        P.wgroups = (vcols + 3) / 4;
         P.gx = gx;
         const long long blocks = (long long)gx * d->N * P.bands;
         BG_CHECK_ARG(blocks <= 0x7fffffffLL, "bg_dwconv3x3_bwd_weight: grid too large");
         BG_DISPATCH_DTYPE(d->dtype, T,
                           hipLaunchKernelGGL((dw_bwd_weight_s1_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, P));
         BG_CHECK_LAUNCH("dw_bwd_weight_s1_kernel");
+        return BG_OK;
+    }
+    if (d->stride == 2 && d->dil == 1 && !old11 && !old_sd) {
+        BG_CHECK_ARG((long long)d->W * d->ldx * 4 < 0x7fffffffLL && (long long)d->Wo * d->ldy * 4 < 0x7fffffffLL,
+                     "bg_dwconv3x3_bwd_weight: image row too large");
+        P.rows_per_block = 4 < d->Ho ? 4 : d->Ho;
+        P.bands = (d->Ho + P.rows_per_block - 1) / P.rows_per_block;
+        P.gx = gx;
+        const long long blocks = (long long)gx * d->N * P.bands;
+        BG_CHECK_ARG(blocks <= 0x7fffffffLL, "bg_dwconv3x3_bwd_weight: grid too large");
+        BG_DISPATCH_DTYPE(d->dtype, T,
+                          hipLaunchKernelGGL((dw_bwd_weight_s2_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+        BG_CHECK_LAUNCH("dw_bwd_weight_s2_kernel");
         return BG_OK;
     }
     P.rows_total = d->N * d->Ho;

@@ -170,7 +170,8 @@ def test_conv_mfma_layout_asymmetric(dtype):
     assert torch.equal(from_nhwc(yb, c), F.conv2d(x, wt))  # small integers: exact in bf16 too
 
 
-DW_CASES = [(2, 13, 18, 16, 1, 1), (2, 12, 10, 24, 2, 1), (1, 9, 7, 728, 1, 1), (2, 9, 7, 40, 1, 2), (1, 7, 5, 8, 2, 1)]
+DW_CASES = [(2, 13, 18, 16, 1, 1), (2, 12, 10, 24, 2, 1), (1, 9, 7, 728, 1, 1), (2, 9, 7, 40, 1, 2), (1, 7, 5, 8, 2, 1),
+            (2, 16, 12, 24, 1, 2), (2, 11, 13, 40, 2, 1), (1, 20, 18, 264, 2, 1)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
