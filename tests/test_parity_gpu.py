@@ -351,6 +351,51 @@ def test_full_size_properties_bf16():
     assert rel_err(g_sum.cpu(), g_all.cpu()) <= 2e-2  # float atomics order + bf16 re-rounding of activations
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_step_schedules_agree(dtype):
+    """The step's scheduling choices are results-neutral: D(real)+D(fake) as one batched pass with per-half
+    BatchNorm statistics, the G-step forward issued early on the side stream, weight gradients on their own
+    stream -- against the plain sequential schedule, same seeds and labels.  fp32: agreement to float-atomic
+    summation order; bf16 (the measured dtype, 256x256x16): to storage rounding."""
+    c, h, w, n = (4, 64, 64, 2) if dtype == F32 else (16, 256, 256, 4)
+
+    def run(plain):
+        G, _ = build_generator(c, 31, dtype)
+        D, _ = build_discriminator(c, h, w, 32, dtype)
+        G.train(), D.train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        tr = GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5),
+                        ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5), crit, losses.L1Loss())
+        if plain:
+            tr._batched_d, tr._g_ahead_ok, tr._side = False, False, None
+        torch.manual_seed(3)
+        labels = crit.draw_labels()
+        x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 77))
+        old = ops._WG_ENABLED
+        ops._WG_ENABLED = not plain
+        try:
+            d_loss, g_loss = tr.step(x, y, labels=labels)
+            torch.cuda.synchronize()
+        finally:
+            ops._WG_ENABLED = old
+        sd = D.state_dict()
+        return (float(d_loss), float(g_loss), G.arena().master.double().clone(), D.arena().master.double().clone(),
+                sd["xception_features.bn1.running_mean"].clone(), sd["xception_features.bn1.running_var"].clone(),
+                int(sd["xception_features.bn1.num_batches_tracked"]))
+
+    a, b = run(True), run(False)
+    # d_loss is computed before any update; g_loss after D's first Adam step, which is sign-like (g / |g|): a
+    # gradient element within summation-order noise of zero moves its weight by +-lr either way
+    assert abs(a[0] - b[0]) <= (1e-5 if dtype == F32 else 3e-2) * abs(a[0]), (a[:2], b[:2])
+    assert abs(a[1] - b[1]) <= (2e-3 if dtype == F32 else 5e-2) * abs(a[1]), (a[:2], b[:2])
+    for i in (2, 3):   # weights: at most one sign-like step (2 * lr = 2e-4) apart
+        assert (b[i] - a[i]).abs().max().item() <= 2.5e-4
+    # the third forward (G-step) already runs on the updated weights, hence the same 1e-4 scale
+    assert rel_err(b[4].cpu(), a[4].cpu()) <= (3e-4 if dtype == F32 else 2e-2)
+    assert rel_err(b[5].cpu(), a[5].cpu()) <= (3e-4 if dtype == F32 else 2e-2)
+    assert a[6] == b[6] == 3          # D ran three times on the batch (real, fake, fake again in the G-step)
+
+
 def test_validation_and_checkpoint_roundtrip(tmp_path, golden_dir):
     """train_gan.py:330-431: eval-mode validation leaves the models untouched and in train
     mode; a checkpoint written after a step restores parameters, buffers and Adam state so
