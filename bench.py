@@ -164,8 +164,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         d_loss, g_loss = trainer.step(*batches[i % 2])
+    host_enqueue = time.perf_counter() - t0      # host time to ENQUEUE the steps (no device sync in the loop)
     sync_all()
     elapsed = time.perf_counter() - t0
+    note(f"host enqueue {1e3 * host_enqueue / args.steps:.1f} ms/step")
     note(f"done: {1e3 * elapsed / args.steps:.1f} ms/step")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)

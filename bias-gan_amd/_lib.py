@@ -142,7 +142,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Raw handle of torch's current HIP stream on the current device (the launch path: ~0.3 us through the
+    C accessor instead of ~9 us through the torch.cuda.Stream object)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -207,17 +214,33 @@ def host_call(name, *args):
         raise RuntimeError(f"{name} failed ({rc}): {msg}")
 
 
+_FN = {}
+
+
+def call_on(raw_stream, name, *args):
+    """Call an entry point on an explicit raw HIP stream handle (no change of torch's current stream)."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args, raw_stream)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {_lib.bg_last_error().decode()}")
+
+
 def call(name, *args):
     """Call an entry point on the current HIP stream; raise on a non-zero status."""
-    lib = load()
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    lib = _lib
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = getattr(lib, name)(*args, stream())
+        rc = fn(*args, stream())
         e1.record()
         flops = _conv_flops(args[0]) if name.startswith("bg_conv2d") else 0.0
         PROFILE.append((name, flops, e0, e1, _alg_bytes(name, args)))
     else:
-        rc = getattr(lib, name)(*args, stream())
+        rc = fn(*args, stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.bg_last_error().decode()}")

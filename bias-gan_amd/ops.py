@@ -108,40 +108,33 @@ _WG_PENDING = set()
 _WG_ENABLED = not _os.environ.get("BGAMD_NO_WGRAD_STREAM")
 
 
-class _WgradStream:
-    def __init__(self, dev, *tensors):
-        self.dev, self.tensors = dev, tensors
-        self.ctx = None
-
-    def __enter__(self):
-        if not _WG_ENABLED or L.PROFILE is not None:   # the profile step times ONE kernel per event pair
-            return self
-        key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        side = _WG_STREAMS.get(key)
-        if side is None:
-            side = _WG_STREAMS[key] = torch.cuda.Stream(device=self.dev)
-        side.wait_stream(torch.cuda.current_stream(self.dev))
-        if key not in _WG_PENDING:
-            _WG_PENDING.add(key)
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
-        for t in self.tensors:
-            t.record_stream(side)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
+def wgrad_call(dev, tensors, name, *args):
+    """Launch a weight-gradient entry point on the second stream (after everything enqueued so far on the
+    caller's stream); `tensors` are the operands whose memory must outlive that launch."""
+    if not _WG_ENABLED or L.PROFILE is not None:   # the profile step times ONE kernel per event pair
+        L.call(name, *args)
+        return
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _WG_STREAMS.get(key)
+    if ent is None:
+        side = torch.cuda.Stream(device=dev)
+        ent = _WG_STREAMS[key] = (side, side.cuda_stream)
+    side, raw = ent
+    side.wait_stream(torch.cuda.current_stream(dev))
+    if key not in _WG_PENDING:
+        _WG_PENDING.add(key)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
+    for t in tensors:
+        t.record_stream(side)
+    L.call_on(raw, name, *args)   # the kernel only accumulates into the gradient arena: no allocation on that stream
 
 
 def wgrad_join(key=None):
     """Make the current stream wait for the weight-gradient stream(s)."""
     for k in ([key] if key is not None else list(_WG_STREAMS)):
-        side = _WG_STREAMS.get(k)
-        if side is not None:
-            torch.cuda.current_stream(side.device).wait_stream(side)
+        ent = _WG_STREAMS.get(k)
+        if ent is not None:
+            torch.cuda.current_stream(ent[0].device).wait_stream(ent[0])
         _WG_PENDING.discard(k)
 
 
@@ -242,8 +235,7 @@ class Conv2dFn(torch.autograd.Function):
             if bslot is not None and ctx.needs_input_grad[2]:
                 arena.ensure_grad(bslot)
                 dbias = arena.grad_ptr(bslot)
-            with _WgradStream(xdev, x, g):
-                L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
+            wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
         return dx, None, None, None, None, None, None, None, None, None
 
 
@@ -287,8 +279,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             (x,) = ctx.saved_tensors
             arena.ensure_grad(wslot)
             desc = L.ConvDesc(L.dt(xdtype), n, ho, wo, cp, h, w, kp, kh, kw, stride, pad, 1, ld_of(g), ld_of(x))
-            with _WgradStream(xdev, x, g):
-                L.call("bg_conv2d_bwd_weight", desc, g.data_ptr(), x.data_ptr(), arena.grad_ptr(wslot), None)
+            wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, g.data_ptr(), x.data_ptr(), arena.grad_ptr(wslot), None)
         return dx, None, None, None, None, None, None
 
 
@@ -349,8 +340,7 @@ class DwConv3x3Fn(torch.autograd.Function):
             (x,) = ctx.saved_tensors
             arena.ensure_grad(wslot)
             desc = L.DwDesc(L.dt(xdtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(g))
-            with _WgradStream(xdev, x, g):
-                L.call("bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
+            wgrad_call(xdev, (x, g), "bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
         return dx, None, None, None, None, None
 
 
