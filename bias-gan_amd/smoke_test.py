@@ -19,7 +19,10 @@ def run(device="cuda:0", c=4, h=64, w=64, n=2):
     from .utils import parsing_helpers as ph
 
     results = {}
-    for dtype, tol_d, tol_g in ((torch.float32, 1e-3, 2e-2), (torch.bfloat16, 5e-2, 2.5e-1)):
+    # fp32 path: the oracle's own tolerance.  bf16 path: storage rounding through the randomly filled 140-layer
+    # nets reaches 10-20 % at the outputs (tests/test_parity_gpu.py header), and which side of a bf16 rounding
+    # boundary a value lands on changes with the kernels' summation order, so the loss is only pinned loosely.
+    for dtype, tol_d, tol_g in ((torch.float32, 1e-3, 2e-2), (torch.bfloat16, 2e-1, 3e-1)):
         gspec = orc.generator_spec(c, c, 0, "batch")
         dspec = orc.discriminator_spec(c, h, w, "batch")
         sg, sd = orc.fill_state(gspec, 21), orc.fill_state(dspec, 22)

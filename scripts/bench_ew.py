@@ -10,7 +10,7 @@ import bias_gan_amd  # noqa: E402,F401
 from bias_gan_amd import _lib as L  # noqa: E402
 
 DEV = torch.device("cuda", 0)
-SHAPES = [(8, 576, 384, 128), (8, 288, 192, 256), (8, 144, 96, 728), (8, 72, 48, 1536)]
+SHAPES = [(8, 576, 384, 128), (8, 288, 192, 256), (8, 144, 96, 728), (8, 72, 48, 728), (16, 72, 48, 728), (8, 72, 48, 1536)]
 only = sys.argv[1:] or None
 
 
