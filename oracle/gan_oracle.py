@@ -292,8 +292,9 @@ def norm(P: State, key: str, x: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
         # (mean = x, var = 0): the unchecked arithmetic of the reference's
         # torch 1.8 era.  torch >= 1.9 raises instead, so
         # compute it directly.
-        m = x.mean(dim=(2, 3), keepdim=True)
-        v = x.var(dim=(2, 3), unbiased=False, keepdim=True)
+        sp = tuple(range(2, x.dim()))  # spatial dims: (2,3) for 2-D nets, (2,3,4) for the 3-D ones
+        m = x.mean(dim=sp, keepdim=True)
+        v = x.var(dim=sp, unbiased=False, keepdim=True)
         return (x - m) / torch.sqrt(v + BN_EPS)
     g, b = P[key + ".weight"], P[key + ".bias"]
     rm, rv = P[key + ".running_mean"], P[key + ".running_var"]

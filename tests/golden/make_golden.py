@@ -32,8 +32,10 @@ sys.dont_write_bytecode = True
 from architecture.gpsro import deeplab as ref_dl  # noqa: E402
 from architecture.gpsro import deeplab_gan as ref_gan  # noqa: E402
 from utils import losses as ref_losses  # noqa: E402
+from architecture.gpsro import deeplab3d_gan as ref_gan3d  # noqa: E402
 
 from oracle import gan_oracle as orc  # noqa: E402  (only for specs / deterministic fills / fields)
+from oracle import gan3d_oracle as orc3  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -351,8 +353,84 @@ def golden_c1_plumbing(c=4, h=64, w=64, n=2, steps=3):
     print("c1", dl, gl)
 
 
+def _load_checked(mod, spec, seed):
+    sd = mod.state_dict()
+    assert [k for k, _, _ in spec] == list(sd.keys()), "key order differs from the reference"
+    for k, shape, _ in spec:
+        assert tuple(sd[k].shape) == tuple(shape), (k, sd[k].shape, shape)
+    mod.load_state_dict(orc.fill_state(spec, seed))
+
+
+def golden_gan3d(c=1, d=16, h=24, w=24, n=2):
+    """3-D DeepLab GAN: Generator (Interpolate upsampler, BatchNorm3d), Discriminator with
+    BatchNorm3d and InstanceNorm3d (the Wasserstein critic, train_gan3d.py:140), per-sample gradient penalty."""
+    res = {}
+    g = ref_gan3d.Generator(c, c, "Interpolate", "Uniform", 0, os=16, pretrained=False, normalizer=nn.BatchNorm3d)
+    gspec = orc3.generator3d_spec(c, c, 0, "batch")
+    _load_checked(g, gspec, 31)
+    g.train()
+    x, y = orc3.synthetic_volumes(n, c, d, h, w, 131)
+    out = g(x)
+    loss = (out - y).abs().mean()
+    loss.backward()
+    res["g::out"], res["g::loss"] = out.detach().numpy(), np.array(loss.item())
+    cs = checksums((k, p.grad) for k, p in g.named_parameters())
+    res["g::grad_keys"], res["g::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+    named = dict(g.named_parameters())
+    for k in ("model.xception_features.conv1.weight", "model.xception_features.bn1.weight",
+              "model.xception_features.block1.rep.0.conv1.weight", "model.upsample.last_conv.6.weight",
+              "model.aspp3.bn.bias", "model.global_avg_pool.2.weight"):
+        res["g::grad::" + k] = named[k].grad.numpy()
+    sd = g.state_dict()
+    for k in ("model.xception_features.bn1.running_mean", "model.xception_features.bn2.running_var",
+              "model.upsample.last_conv.4.running_mean"):
+        res["g::buf::" + k] = sd[k].numpy()
+    g.eval()
+    with torch.no_grad():
+        res["g::out_eval"] = g(x).numpy()
+    # the InstanceNorm3d critic gets a larger volume: on 16x24x24 its deepest maps hold 4 values per channel and
+    # rstd = 1/sqrt(var + 1e-5) blows rounding noise up to 10 % of the logits (two fp32 evaluations disagree)
+    d2, h2, w2 = 2 * d, 2 * h, 2 * w
+    x_in, _ = orc3.synthetic_volumes(n, c, d2, h2, w2, 133)
+    for tag, norm_cls, kind, seed in (("d_bn", nn.BatchNorm3d, "batch", 32), ("d_in", nn.InstanceNorm3d, "instance", 33)):
+        dm = ref_gan3d.Discriminator(n_input=c, os=16, pretrained=False, normalizer=norm_cls)
+        dspec = orc3.discriminator3d_spec(c, kind)
+        _load_checked(dm, dspec, seed)
+        dm.train()
+        xd = (x if tag == "d_bn" else x_in).clone().requires_grad_(True)
+        logits, pred = dm(xd)
+        tgt = torch.linspace(0.1, 0.9, n).reshape(-1, 1)
+        dl = nn.functional.binary_cross_entropy_with_logits(logits, tgt)
+        dl.backward()
+        res[f"{tag}::logits"], res[f"{tag}::pred"] = logits.detach().numpy(), pred.detach().numpy()
+        res[f"{tag}::loss"], res[f"{tag}::dx"] = np.array(dl.item()), xd.grad.numpy()
+        cs = checksums((k, p.grad) for k, p in dm.named_parameters())
+        res[f"{tag}::grad_keys"], res[f"{tag}::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+        res[f"{tag}::grad::linear.weight"] = dict(dm.named_parameters())["linear.weight"].grad.numpy()
+        if tag == "d_in":
+            # gradient penalty with the critic above: eta comes from the host RNG (deeplab3d_gan.py:105-106)
+            fake, real = orc3.synthetic_volumes(n, c, d2, h2, w2, 132)
+            torch.manual_seed(77)
+            gp = ref_gan3d.gradient_penalty(dm, fake, real)
+            torch.manual_seed(77)
+            eta = torch.distributions.uniform.Uniform(0., 1.).rsample((n, 1, 1, 1, 1))
+            res["gp::value"], res["gp::eta"] = np.array(gp.item()), eta.numpy()
+            assert not gp.requires_grad
+    np.savez_compressed(os.path.join(HERE, "gan3d_c1_16x24x24.npz"),
+                        meta=json.dumps(dict(c=c, d=d, h=h, w=w, n=n, g_seed=31, d_bn_seed=32, d_in_seed=33,
+                                             field_seed=131, gp_field_seed=132, in_dhw=[d2, h2, w2], in_field_seed=133)),
+                        **res)
+    with open(os.path.join(HERE, "state_dict_keys_3d.json"), "w") as f:
+        json.dump({"generator3d_c1": [[k, list(v.shape)] for k, v in g.state_dict().items()],
+                   "discriminator3d_c1_bn": [[k, s_] for k, s_ in
+                                             [(k, list(sh)) for k, sh, _ in orc3.discriminator3d_spec(c, "batch")]]}, f)
+    print("gan3d goldens written: g loss", float(res["g::loss"]), "gp", float(res["gp::value"]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
+    if "all" in which or "gan3d" in which:
+        golden_gan3d()
     if "all" in which or "keys" in which:
         g, gs = build_ref_generator(16, nn.BatchNorm2d, 0)
         d, ds = build_ref_discriminator(16, 64, 64, nn.BatchNorm2d, 0)
