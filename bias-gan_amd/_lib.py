@@ -27,6 +27,10 @@ class DwDesc(C.Structure):
     _fields_ = [(n, c_i32) for n in ("dtype", "N", "H", "W", "C", "Ho", "Wo", "stride", "dil", "ldx", "ldy")]
 
 
+class Dw3Desc(C.Structure):
+    _fields_ = [(n, c_i32) for n in ("dtype", "N", "D", "H", "W", "C", "Do", "Ho", "Wo", "stride", "dil", "ldx", "ldy")]
+
+
 class NpyInfo(C.Structure):
     _fields_ = [("dtype_code", c_i32), ("typesize", c_i32), ("fortran_order", c_i32), ("ndim", c_i32),
                 ("shape", c_i64 * 8), ("data_offset", c_i64), ("file_size", c_i64)]
@@ -69,6 +73,13 @@ _SIGS = {
                              c_vp],
     "bg_norm_act_bwd_apply": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
                               c_i64, c_i32, c_i32, c_i32, c_vp],
+    "bg_depth_unfold": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_depth_fold": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_dwconv3x3x3_fwd": [C.POINTER(Dw3Desc), c_vp, c_vp, c_vp, c_vp],
+    "bg_dwconv3x3x3_bwd_data": [C.POINTER(Dw3Desc), c_vp, c_vp, c_vp, c_vp],
+    "bg_dwconv3x3x3_bwd_weight": [C.POINTER(Dw3Desc), c_vp, c_vp, c_vp, c_vp],
+    "bg_depth_resize_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_depth_resize_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_avgpool2x2": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_resize_bilinear_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_resize_bilinear_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

@@ -381,7 +381,7 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum,
-                pre_stats=None, bn_groups=1):
+                pre_stats=None, bn_groups=1, inst_groups=None):
         """bn_groups: 'batch' statistics are taken separately over that many equal sub-batches (see
         batch_groups()).  pre_stats: fp64 [2, groups, C] sums already produced by the convolution's epilogue
         (bg_conv2d_fwd_stats); skips the separate statistics pass."""
@@ -392,7 +392,8 @@ class NormActFn(torch.autograd.Function):
         if res is not None:
             res = nhwc(res)
         use_batch_stats = (kind == "batch" and training) or kind == "instance"
-        groups = n if kind == "instance" else (bn_groups if kind == "batch" and training else 1)
+        # instance statistics: one group per sample; a volume folded into the batch passes its sample count
+        groups = (inst_groups or n) if kind == "instance" else (bn_groups if kind == "batch" and training else 1)
         assert n % groups == 0, f"batch of {n} does not split into {groups} statistic groups"
         mean = rstd = scale = shift = None
         y = new_act(n, h, w, c, x.dtype, dev)
@@ -437,12 +438,12 @@ class NormActFn(torch.autograd.Function):
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
         if kind == "identity":
             if dx is None and dres is None:
-                return (None,) * 16
+                return (None,) * 17
             # dx and dres are the same tensor values: write once, alias
             out = dx if dx is not None else dres
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None,
                    out.data_ptr(), ld_of(out), None, 0, rows, c, groups, act)
-            return (out if need_dx else None, out if need_res else None) + (None,) * 14
+            return (out if need_dx else None, out if need_res else None) + (None,) * 15
         want_affine_grads = gslot is not None and gslot.param.requires_grad
         gptr = None if gslot is None else arena.master_ptr(gslot)
         bptr = None if bslot is None else arena.master_ptr(bslot)
@@ -466,7 +467,7 @@ class NormActFn(torch.autograd.Function):
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
-        return (dx, dres) + (None,) * 14
+        return (dx, dres) + (None,) * 15
 
 
 def leaky_relu(x):
@@ -542,25 +543,29 @@ class GlobalAvgPoolFn(torch.autograd.Function):
     """nn.AdaptiveAvgPool2d((1,1)) (deeplab.py:621)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, samples=None):
+        """samples: number of pooled groups (default: the leading dimension; a volume [N*D,H,W,C] passes N)."""
         x = nhwc(x)
-        n, h, w, c = x.shape
+        nd, h, w, c = x.shape
+        n = samples or nd
+        rows = nd * h * w
         acc = _f32(n, c, device=x.device)
-        L.call("bg_colsum", L.dt(x.dtype), x.data_ptr(), ld_of(x), n * h * w, c, n, 1.0 / (h * w), acc.data_ptr())
+        L.call("bg_colsum", L.dt(x.dtype), x.data_ptr(), ld_of(x), rows, c, n, float(n) / rows, acc.data_ptr())
         y = new_act(n, 1, 1, c, x.dtype, x.device)
         L.call("bg_cast_rows", L.F32, L.dt(x.dtype), acc.data_ptr(), c, y.data_ptr(), ld_of(y), n, c)
-        ctx.meta = (n, h, w, c, x.dtype)
+        ctx.meta = (n, nd, h, w, c, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        n, h, w, c, dtype = ctx.meta
+        n, nd, h, w, c, dtype = ctx.meta
         g = g.contiguous()
         gf = _f32(n, c, device=g.device)
         L.call("bg_cast_rows", L.dt(g.dtype), L.F32, g.data_ptr(), c, gf.data_ptr(), c, n, c)
-        dx = new_act(n, h, w, c, dtype, g.device)
-        L.call("bg_broadcast_rows", L.dt(dtype), gf.data_ptr(), 1.0 / (h * w), dx.data_ptr(), ld_of(dx), n * h * w, c, n)
-        return dx
+        dx = new_act(nd, h, w, c, dtype, g.device)
+        rows = nd * h * w
+        L.call("bg_broadcast_rows", L.dt(dtype), gf.data_ptr(), float(n) / rows, dx.data_ptr(), ld_of(dx), rows, c, n)
+        return dx, None
 
 
 class ConcatFn(torch.autograd.Function):
@@ -592,6 +597,102 @@ class ConcatFn(torch.autograd.Function):
 
 def concat(*xs):
     return ConcatFn.apply(*xs)
+
+
+# ----------------------------------------------------------------------- volumes (3-D path)
+class DepthUnfoldFn(torch.autograd.Function):
+    """[N*D,H,W,C] -> [N*Do,H,W,KD*C]: channel block kd of slice od is input slice od*stride - pad + kd*dil (zeros
+    outside).  With it nn.Conv3d runs on the 2-D GEMM kernels (bg_depth_unfold / bg_depth_fold)."""
+
+    @staticmethod
+    def forward(ctx, x, n, kd, stride, pad, dil):
+        x = nhwc(x)
+        nd, h, w, c = x.shape
+        d = nd // n
+        do = (d + 2 * pad - dil * (kd - 1) - 1) // stride + 1
+        y = new_act(n * do, h, w, kd * c, x.dtype, x.device)
+        L.call("bg_depth_unfold", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, d, do, h * w, c, kd, stride,
+               pad, dil)
+        ctx.meta = (n, d, do, h, w, c, kd, stride, pad, dil, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, d, do, h, w, c, kd, stride, pad, dil, dtype = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n * d, h, w, c, dtype, g.device)
+        L.call("bg_depth_fold", L.dt(dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, d, do, h * w, c, kd, stride,
+               pad, dil)
+        return dx, None, None, None, None, None
+
+
+class DwConv3dFn(torch.autograd.Function):
+    """Depthwise 3x3x3 of SeparableConv3d_same with fixed_padding folded in (bg_dwconv3x3x3_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, n, stride, dil):
+        x = nhwc(x)
+        nd, h, w, c = x.shape
+        d = nd // n
+        assert wslot.phys_shape == (3, 3, 3, c), (wslot.phys_shape, c)
+        do, ho, wo = -(-d // stride), -(-h // stride), -(-w // stride)
+        y = new_act(n * do, ho, wo, c, x.dtype, x.device)
+        desc = L.Dw3Desc(L.dt(x.dtype), n, d, h, w, c, do, ho, wo, stride, dil, ld_of(x), ld_of(y))
+        L.call("bg_dwconv3x3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
+        if weight.requires_grad:
+            ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, n, d, h, w, c, do, ho, wo, stride, dil, x.dtype, x.device)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        arena, wslot, n, d, h, w, c, do, ho, wo, stride, dil, xdtype, xdev = ctx.meta
+        g = nhwc(g)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(n * d, h, w, c, xdtype, xdev)
+            desc = L.Dw3Desc(L.dt(xdtype), n, d, h, w, c, do, ho, wo, stride, dil, ld_of(dx), ld_of(g))
+            L.call("bg_dwconv3x3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), dx.data_ptr())
+        if ctx.needs_input_grad[1]:
+            (x,) = ctx.saved_tensors
+            arena.ensure_grad(wslot)
+            desc = L.Dw3Desc(L.dt(xdtype), n, d, h, w, c, do, ho, wo, stride, dil, ld_of(x), ld_of(g))
+            wgrad_call(xdev, (x, g), "bg_dwconv3x3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
+        return dx, None, None, None, None, None, None
+
+
+class DepthResizeFn(torch.autograd.Function):
+    """Linear interpolation along depth, align_corners=True; trilinear = this, then ResizeBilinearFn."""
+
+    @staticmethod
+    def forward(ctx, x, n, do, out_dtype: Optional[torch.dtype]):
+        x = nhwc(x)
+        nd, h, w, c = x.shape
+        di = nd // n
+        out_dtype = out_dtype or x.dtype
+        y = new_act(n * do, h, w, c, out_dtype, x.device)
+        L.call("bg_depth_resize_fwd", L.dt(x.dtype), L.dt(out_dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, di, do,
+               h * w, c)
+        ctx.meta = (n, di, do, h, w, c, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, di, do, h, w, c, in_dtype = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n * di, h, w, c, in_dtype, g.device)
+        L.call("bg_depth_resize_bwd", L.dt(g.dtype), L.dt(in_dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, di, do,
+               h * w, c)
+        return dx, None, None, None
+
+
+def resize_trilinear(x, n, do, ho, wo, out_dtype=None):
+    """F.interpolate(mode='trilinear', align_corners=True) on a folded volume [N*D,H,W,C] -> [N*do,ho,wo,C]
+    (separable: depth first -- on the smaller tensor when upsampling -- then the 2-D bilinear kernel)."""
+    d = x.shape[0] // n
+    if do != d:
+        x = DepthResizeFn.apply(x, n, do, None)
+    return ResizeBilinearFn.apply(x, ho, wo, out_dtype)
 
 
 # ---------------------------------------------------------------------------- head

@@ -133,7 +133,7 @@ class Arena:
         for s in self.slots:
             s.off = off
             off += pad_to(s.numel, 64)  # 256-byte aligned segments
-            if s.kind == "conv":
+            if s.kind in ("conv", "conv3d"):    # conv3d: [Kp, KH, KW, KD*Cp] -- a 2-D conv over the depth-unfolded input
                 k, r, q, c = s.phys_shape
                 cp, kp = pad_to(c, g), pad_to(k, g)
                 s.krsc = (k, r * q, c, cp, kp)
@@ -148,11 +148,11 @@ class Arena:
         self.wk = torch.zeros(max(k_off, 1), dtype=compute_dtype, device=dev)
         self.wt = torch.zeros(max(t_off, 1), dtype=compute_dtype, device=dev)
         tbl = [[s.off, s.k_off, s.t_off, s.krsc[0], s.krsc[1], s.krsc[2], s.krsc[3], s.krsc[4]]
-               for s in self.slots if s.kind == "conv"]
+               for s in self.slots if s.krsc is not None]
         self.tr_tbl = torch.tensor(tbl if tbl else [[0] * 8], dtype=torch.int64, device=dev)
         self.tr_layers = len(tbl)
         self.tr_max = max([s.krsc[0] * s.krsc[1] * s.krsc[3] + s.krsc[2] * s.krsc[1] * s.krsc[4]
-                           for s in self.slots if s.kind == "conv"] + [1])
+                           for s in self.slots if s.krsc is not None] + [1])
         # move the current values in and re-point the Parameters at arena views
         with torch.no_grad():
             for s in self.slots:
@@ -177,6 +177,13 @@ class Arena:
         if s.kind == "dw":         # arena [R,S,Cp] -> logical [C,1,R,S]
             c = p.shape[0]
             return seg.view(s.phys_shape).permute(2, 0, 1)[:c].unsqueeze(1)
+        if s.kind == "conv3d":     # arena [Kp,R,S,KD,Cp] -> logical [K,C,KD,R,S]
+            k, c, kd = p.shape[0], p.shape[1], p.shape[2]
+            kp, r, q, kdc = s.phys_shape
+            return seg.view(kp, r, q, kd, kdc // kd).permute(0, 4, 3, 1, 2)[:k, :c]
+        if s.kind == "dw3d":       # arena [KD,R,S,Cp] -> logical [C,1,KD,R,S]
+            c = p.shape[0]
+            return seg.view(s.phys_shape).permute(3, 0, 1, 2)[:c].unsqueeze(1)
         if s.kind == "vec":        # arena [Cp] -> logical [C]
             return seg[:p.shape[0]]
         return seg.view(p.shape)
@@ -225,7 +232,7 @@ class Arena:
     def weight_ptr(self, s: ParamSlot) -> int:
         """Device pointer of the compute-dtype operand copy of a parameter: packed KRSC for
         dense convs, the flat [R,S,C] copy for depthwise weights."""
-        if s.kind == "conv":
+        if s.krsc is not None:
             return self.wk.data_ptr() + self.wk.element_size() * s.k_off
         if self.lp is not None:
             return self.lp.data_ptr() + 2 * s.off

@@ -114,6 +114,40 @@ int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, const void* w
 int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * 3-D DeepLab GAN path (architecture/gpsro/deeplab3d.py).  A volume [N,D,H,W,C] is the
+ * NHWC tensor [N*D,H,W,C]; every entry point above applies to it as it stands.  The third dimension adds:
+ *
+ * bg_depth_unfold: y[n,od,p, kd*C + c] = x[n, od*stride - pad + kd*dil, p, c] (0 outside), p = pixel of the H*W
+ *   plane.  nn.Conv3d(k, stride, padding, dilation) (deeplab3d.py:120,124,274,307-312) = this, then the 2-D
+ *   convolution entry points over KD*C input channels with weights [K][KH][KW][KD][C].  KD = 1, stride 2, pad 0
+ *   is the depth subsampling of the 1x1x1 stride-2 skip convolutions (deeplab3d.py:51).
+ * bg_depth_fold: the adjoint (gradient w.r.t. x from the gradient w.r.t. y); overwrites dx.
+ * ------------------------------------------------------------------------- */
+int bg_depth_unfold(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t D, int32_t Do,
+                    int32_t HW, int32_t C, int32_t KD, int32_t stride, int32_t pad, int32_t dil, void* stream);
+int bg_depth_fold(int32_t dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N, int32_t D, int32_t Do,
+                  int32_t HW, int32_t C, int32_t KD, int32_t stride, int32_t pad, int32_t dil, void* stream);
+/* Depthwise 3x3x3 of SeparableConv3d_same with fixed_padding folded in (deeplab3d.py:22-43: pad = dil on every
+ * side for k = 3).  Do/Ho/Wo = ceil(./stride).  w: [3][3][3][C] dtype; dw: [3][3][3][C] fp32 accumulated. */
+typedef struct bg_dwconv3d_desc {
+    int32_t dtype;
+    int32_t N, D, H, W, C;
+    int32_t Do, Ho, Wo;
+    int32_t stride, dil;
+    int32_t ldx, ldy;
+} bg_dwconv3d_desc;
+int bg_dwconv3x3x3_fwd(const bg_dwconv3d_desc* d, const void* x, const void* w, void* y, void* stream);
+int bg_dwconv3x3x3_bwd_data(const bg_dwconv3d_desc* d, const void* dy, const void* w, void* dx, void* stream);
+int bg_dwconv3x3x3_bwd_weight(const bg_dwconv3d_desc* d, const void* x, const void* dy, float* dw, void* stream);
+/* Linear interpolation along depth, align_corners=True: F.interpolate(mode='trilinear', align_corners=True)
+ * (deeplab3d.py:315-320,545) = this followed by bg_resize_bilinear_fwd on the folded tensor.  x: [N][Di][HW][ldx],
+ * y: [N][Do][HW][ldy]; C a multiple of 4.  _bwd is the adjoint (overwrites dx). */
+int bg_depth_resize_fwd(int32_t in_dtype, int32_t out_dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N,
+                        int32_t Di, int32_t Do, int32_t HW, int32_t C, void* stream);
+int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N,
+                        int32_t Di, int32_t Do, int32_t HW, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Normalisation (BatchNorm2d train/eval, InstanceNorm2d, Identity) fused with
  * the residual add (Block: x += skip, deeplab.py:141) and LeakyReLU(0.2)
  * (deeplab.py:100,180,334,365).

@@ -1,0 +1,202 @@
+"""3-D path on the MI355X, through the C ABI: the volume kernels against torch fp32
+evaluations of the same ops, and the 3-D Generator / Discriminator / gradient penalty against vectors produced
+by the reference's own modules (tests/golden/gan3d_c1_16x24x24.npz).  Tolerances as in test_kernels_gpu.py /
+test_parity_gpu.py: kernels 1e-4 (fp32) / 1e-2 (bf16) of the reference's max; full nets fp32 forward 2e-4,
+gradients rms 3e-2 (kinked activations, see test_parity_gpu.py), bf16 rms 3e-1."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import bias_gan_amd  # noqa: F401
+from bias_gan_amd import ops
+from bias_gan_amd.architecture.gpsro import deeplab3d as d3
+from bias_gan_amd.architecture.gpsro import deeplab3d_gan as g3
+from bias_gan_amd.runtime import pad_to, vec_of
+from oracle import gan3d_oracle as o3  # checker only
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def rnd(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).float()
+
+
+def tol(dtype):
+    return 1e-4 if dtype == F32 else 1e-2
+
+
+def close(got, ref, rel, what=""):
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rel})"
+
+
+def rms(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("case", [(3, 1, 1, 1), (3, 2, 1, 1), (1, 2, 0, 1), (3, 1, 2, 2), (1, 1, 0, 1), (3, 1, 6, 6)])
+def test_conv3d_via_depth_unfold(dtype, case):
+    """nn.Conv3d = depth unfold + 2-D GEMM convolution over KD*C channels: forward, input and weight gradients."""
+    k, s, p, dil = case
+    n, cin, cout, d, h, w = 2, 24, 40, 5, 9, 7
+    m = d3.Conv3d(cin, cout, k, stride=s, padding=p, dilation=dil, bias=False).set_compute_dtype(dtype)
+    wt = rnd((cout, cin, k, k, k), 1, dtype, 1.0 / np.sqrt(cin * k ** 3))
+    m.weight.data.copy_(wt)
+    m.to(DEV)
+    x = rnd((n, cin, d, h, w), 2, dtype)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wr, None, s, p, dil)
+    go = rnd(tuple(ref.shape), 3, dtype)
+    ref.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    y = d3.from_folded(m(d3.to_folded(xd, pad_to(cin, vec_of(dtype)), dtype), n), n, cout)
+    assert tuple(y.shape) == tuple(ref.shape)
+    close(y.detach().cpu(), ref.detach(), tol(dtype), "y")
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    close(xd.grad.cpu(), xr.grad, 2 * tol(dtype), "dx")
+    close(m.weight.grad.cpu(), wr.grad, 5e-4 if dtype == F32 else 2e-2, "dw")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("stride,dil", [(1, 1), (2, 1), (1, 2)])
+def test_dwconv3d_same(dtype, stride, dil):
+    """SeparableConv3d_same's depthwise stage: fixed_padding + grouped conv3d (deeplab3d.py:22-43)."""
+    n, c, d, h, w = 2, 24, 6, 7, 9
+    m = d3.Conv3d(c, c, 3, stride, 0, dil, groups=c, bias=False).set_compute_dtype(dtype)
+    wt = rnd((c, 1, 3, 3, 3), 4, dtype, 0.3)
+    m.weight.data.copy_(wt)
+    m.to(DEV)
+    x = rnd((n, c, d, h, w), 5, dtype)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    tot = 2 * dil
+    beg, end = tot // 2, tot - tot // 2
+    ref = F.conv3d(F.pad(xr, (beg, end) * 3), wr, None, stride, 0, dil, groups=c)
+    go = rnd(tuple(ref.shape), 6, dtype)
+    ref.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    y = d3.from_folded(m(d3.to_folded(xd, pad_to(c, vec_of(dtype)), dtype), n), n, c)
+    assert tuple(y.shape) == tuple(ref.shape)
+    close(y.detach().cpu(), ref.detach(), tol(dtype), "y")
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    close(xd.grad.cpu(), xr.grad, 2 * tol(dtype), "dx")
+    close(m.weight.grad.cpu(), wr.grad, 5e-4 if dtype == F32 else 2e-2, "dw")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("size", [(6, 10, 9), (2, 5, 4), (3, 7, 7)])
+def test_trilinear_align_corners(dtype, size):
+    n, c, d, h, w = 2, 8, 3, 5, 4
+    x = rnd((n, c, d, h, w), 7, dtype).requires_grad_(True)
+    ref = F.interpolate(x, size=size, mode="trilinear", align_corners=True)
+    go = rnd(tuple(ref.shape), 8, dtype)
+    ref.backward(go)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = d3.from_folded(ops.resize_trilinear(d3.to_folded(xd, pad_to(c, vec_of(dtype)), dtype), n, *size), n, c)
+    close(y.detach().cpu(), ref.detach(), tol(dtype), "y")
+    y.backward(go.to(DEV))
+    close(xd.grad.cpu(), x.grad, 2 * tol(dtype), "dx")
+    # a single-slice source is broadcast along depth (the global-pool branch of DeepLab3d)
+    x1 = rnd((n, c, 1, 1, 1), 9, dtype)
+    y1 = d3.from_folded(ops.resize_trilinear(d3.to_folded(x1.to(DEV), pad_to(c, vec_of(dtype)), dtype), n, 2, 3, 2), n, c)
+    close(y1.cpu(), F.interpolate(x1, size=(2, 3, 2), mode="trilinear", align_corners=True), tol(dtype), "broadcast")
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "gan3d_c1_16x24x24.npz"))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_generator3d_vs_reference_golden(z, dtype):
+    m = json.loads(str(z["meta"]))
+    spec = o3.generator3d_spec(m["c"], m["c"], 0, "batch")
+    G = g3.Generator(m["c"], m["c"], "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm3d, compute_dtype=dtype)
+    G.load_state_dict(o3.fill_state(spec, m["g_seed"]))
+    G.to(DEV).train()
+    x, y = o3.synthetic_volumes(m["n"], m["c"], m["d"], m["h"], m["w"], m["field_seed"])
+    out = G(x.to(DEV))
+    assert out.shape == tuple(z["g::out"].shape) and out.dtype == torch.float32
+    ref = torch.from_numpy(z["g::out"])
+    r = rms(out.detach().cpu(), ref)
+    print(f"generator3d {dtype}: fwd rms-rel {r:.2e}")
+    if dtype == F32:
+        close(out.detach().cpu(), ref, 2e-4, "out")
+    else:
+        # bf16 storage through the 140-layer net with a 1x2x2 bottleneck at N = 2 (BatchNorm over 8 values per
+        # channel): rounding-boundary flips reach the 30 % level at the output (test_parity_gpu.py header); 3.2e-1 measured
+        assert r <= 5e-1
+    loss = (out - y.to(DEV)).abs().mean()
+    assert abs(loss.item() - float(z["g::loss"])) <= (1e-5 if dtype == F32 else 1e-1) * float(z["g::loss"])
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(G.named_parameters())
+    worst = 0.0
+    for k in z.files:
+        if k.startswith("g::grad::"):
+            worst = max(worst, rms(named[k[9:]].grad.cpu(), z[k]))
+    print(f"generator3d {dtype}: selected gradients worst rms-rel {worst:.2e}")
+    if dtype == F32:
+        assert worst <= 3e-2
+    else:   # bf16 gradients of this 2-sample, 8-values-per-channel net are not comparable element-wise (see above):
+        assert all(torch.isfinite(p.grad).all() for p in G.parameters())   # per-kernel bf16 accuracy: the tests above
+    sd = G.state_dict()
+    for k in z.files:
+        if k.startswith("g::buf::"):
+            close(sd[k[8:]].cpu(), torch.from_numpy(z[k]), 1e-4 if dtype == F32 else 1e-1, k)
+    assert int(sd["model.xception_features.bn1.num_batches_tracked"]) == 1
+    G.eval()
+    with torch.no_grad():
+        oe = G(x.to(DEV))
+    assert rms(oe.cpu(), z["g::out_eval"]) <= (5e-4 if dtype == F32 else 5e-1)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("tag,kind", [("d_bn", "batch"), ("d_in", "instance")])
+def test_discriminator3d_vs_reference_golden(z, tag, kind, dtype):
+    m = json.loads(str(z["meta"]))
+    norm = nn.BatchNorm3d if kind == "batch" else nn.InstanceNorm3d
+    D = g3.Discriminator(m["c"], normalizer=norm, compute_dtype=dtype)
+    D.load_state_dict(o3.fill_state(o3.discriminator3d_spec(m["c"], kind), m["d_bn_seed" if kind == "batch" else "d_in_seed"]))
+    D.to(DEV).train()
+    if kind == "batch":
+        x, _ = o3.synthetic_volumes(m["n"], m["c"], m["d"], m["h"], m["w"], m["field_seed"])
+    else:
+        x, _ = o3.synthetic_volumes(m["n"], m["c"], *m["in_dhw"], m["in_field_seed"])
+    xd = x.to(DEV).requires_grad_(True)
+    logits, pred = D(xd)
+    lt = (1e-4 if kind == "batch" else 2e-3) if dtype == F32 else 2e-1
+    close(logits.detach().cpu(), torch.from_numpy(z[f"{tag}::logits"]), lt, "logits")
+    tgt = torch.linspace(0.1, 0.9, m["n"]).reshape(-1, 1).to(DEV)
+    loss = F.binary_cross_entropy_with_logits(logits, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    r = rms(xd.grad.cpu(), z[f"{tag}::dx"])
+    print(f"discriminator3d {tag} {dtype}: dx rms-rel {r:.2e}")
+    assert r <= (3e-2 if dtype == F32 else 1.5) and torch.isfinite(xd.grad).all()
+    if dtype == F32:
+        close(D.linear.weight.grad.cpu(), torch.from_numpy(z[f"{tag}::grad::linear.weight"]), 2e-3, "dW linear")
+
+
+def test_gradient_penalty3d(z):
+    m = json.loads(str(z["meta"]))
+    D = g3.Discriminator(m["c"], normalizer=nn.InstanceNorm3d, compute_dtype=F32)
+    D.load_state_dict(o3.fill_state(o3.discriminator3d_spec(m["c"], "instance"), m["d_in_seed"]))
+    D.to(DEV).train()
+    fake, real = o3.synthetic_volumes(m["n"], m["c"], *m["in_dhw"], m["gp_field_seed"])
+    gp = g3.gradient_penalty(D, fake.to(DEV), real.to(DEV), torch.from_numpy(z["gp::eta"]))
+    assert not gp.requires_grad
+    assert abs(gp.item() - float(z["gp::value"])) <= 5e-2 * float(z["gp::value"])
+    assert all(p.requires_grad for p in D.parameters())
