@@ -26,7 +26,7 @@ class GANTrainer:
     def __init__(self, generator, discriminator, g_opt, d_opt, criterion_gan, criterion_regression,
                  loss_type_gan="ModifiedMinMax", loss_weight_gan=1.0, loss_weight_regression=1.0, loss_weight_gp=10.0,
                  enable_masks=False, generator_warmup_steps=0, g_scheduler=None, d_scheduler=None,
-                 update_frequency_generator=1, update_frequency_discriminator=1):
+                 update_frequency_generator=1, update_frequency_discriminator=1, gradient_penalty_fn=None):
         self.generator, self.discriminator = generator, discriminator
         self.g_opt, self.d_opt = g_opt, d_opt
         self.criterion_gan, self.criterion_regression = criterion_gan, criterion_regression
@@ -38,6 +38,10 @@ class GANTrainer:
         self.freq_g, self.freq_d = update_frequency_generator, update_frequency_discriminator
         self.step_count = 0
         self._d_pending = False
+        self._gp = gradient_penalty_fn or dxg.gradient_penalty
+        self._train_d = self._train_g = True   # False: evaluate the losses only (train_gan3d.py's update schedule)
+        self.d_loss_scale = 1.0                # train_gan3d.py:306 multiplies d_loss by loss_weight_gan
+        self.last_d_acc = None                 # 0.5 * (acc(real) + acc(fake)) of the last D-step (device scalar)
         # the generator forward of the D-step has no data dependence on D(real): run them on two HIP
         # streams so the tails of one network's kernels overlap the other's (BGAMD_NO_SIDE_STREAM=1 disables)
         import os
@@ -55,6 +59,12 @@ class GANTrainer:
 
     # -- train_gan.py:250-271 -------------------------------------------------------------
     def d_step(self, inputs, outputs_real, labels=None, eta=None):
+        if not self._train_d:                       # losses / accuracy only: no graph
+            with torch.no_grad():
+                outputs_fake = self.generator(inputs)
+                logits_real, _ = self.discriminator(outputs_real)
+                logits_fake, _ = self.discriminator(outputs_fake)
+            return self._d_update(logits_real, logits_fake, outputs_fake, outputs_real, labels, eta)
         if self._batched_d and inputs.is_cuda:
             with torch.no_grad():                   # no graph through G: D's update cannot use it
                 outputs_fake = self.generator(inputs)
@@ -92,7 +102,13 @@ class GANTrainer:
         else:
             d_loss = self.criterion_gan.d_loss(logits_real, logits_fake)
         if self.loss_type_gan == "Wasserstein":
-            d_loss = d_loss + self.w_gp * dxg.gradient_penalty(_unwrap(self.discriminator), outputs_fake, outputs_real, eta)
+            d_loss = d_loss + self.w_gp * self._gp(_unwrap(self.discriminator), outputs_fake, outputs_real, eta)
+        if self.d_loss_scale != 1.0:
+            d_loss = d_loss * self.d_loss_scale
+        with torch.no_grad():   # utils/metrics.py:18-32 with labels 1 / 0: sigmoid(logit) > 0.5  <=>  logit > 0
+            self.last_d_acc = 0.5 * ((logits_real > 0).float().mean() + (logits_fake <= 0).float().mean())
+        if not self._train_d:
+            return d_loss.detach()
         self.d_opt.zero_grad()
         d_loss.backward()
         if isinstance(self.discriminator, DistributedModel):
@@ -109,6 +125,16 @@ class GANTrainer:
 
     # -- train_gan.py:273-298 -------------------------------------------------------------
     def g_step(self, inputs, outputs_real, masks=None):
+        if not self._train_g:                       # loss only
+            self._g_ahead = None
+            self._finish_d()
+            with torch.no_grad():
+                outputs_fake = self.generator(inputs)
+                logits_fake, _ = self.discriminator(outputs_fake)
+                gan_loss = self.criterion_gan.g_loss(logits_fake)
+                reg = (self.criterion_regression(outputs_fake, outputs_real, masks) if self.enable_masks
+                       else self.criterion_regression(outputs_fake, outputs_real))
+            return reg if self.step_count < self.warmup else self.w_gan * gan_loss + self.w_reg * reg
         for p in self._d_params:                    # D is only differentiated w.r.t. its input here
             p.requires_grad_(False)
         try:

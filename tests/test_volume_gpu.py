@@ -200,3 +200,56 @@ def test_gradient_penalty3d(z):
     assert not gp.requires_grad
     assert abs(gp.item() - float(z["gp::value"])) <= 5e-2 * float(z["gp::value"])
     assert all(p.requires_grad for p in D.parameters())
+
+
+def test_trainer3d_schedule_and_updates():
+    """GANTrainer3d: losses every iteration, updates per schedule (train_gan3d.py:270-293): with acc_max = -1 the
+    discriminator is always 'too good' (only G updates), with acc_min = 2 always 'too bad' (only D updates)."""
+    from bias_gan_amd.gpsro_train.train_gan3d import GANTrainer3d
+    from bias_gan_amd.utils import losses
+    from bias_gan_amd.utils import parsing_helpers as ph
+    n, c, d, h, w = 2, 1, 16, 24, 24
+    x, y = (t.to(DEV) for t in o3.synthetic_volumes(n, c, d, h, w, 5))
+
+    def make(schedule):
+        G = g3.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm3d, compute_dtype=F32)
+        D = g3.Discriminator(c, normalizer=nn.BatchNorm3d, compute_dtype=F32)
+        G.load_state_dict(o3.fill_state(o3.generator3d_spec(c, c, 0, "batch"), 41))
+        D.load_state_dict(o3.fill_state(o3.discriminator3d_spec(c, "batch"), 42))
+        G.to(DEV).train(), D.to(DEV).train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        return GANTrainer3d(G, D, ph.get_optimizer(G.parameters(), "Adam", 1e-3, 1e-8, 0.0),
+                            ph.get_optimizer(D.parameters(), "Adam", 1e-3, 1e-8, 0.0), crit, losses.L1Loss(),
+                            loss_weight_gan=0.5, relative_update_schedule=schedule), G, D
+
+    for schedule, g_moves, d_moves in (({"type": "adaptive", "acc_min": 0.0, "acc_max": -1.0}, True, False),
+                                       ({"type": "adaptive", "acc_min": 2.0, "acc_max": 3.0}, False, True),
+                                       ({"type": "static", "update_frequency_generator": 1, "update_frequency_discriminator": 1},
+                                        True, True)):
+        tr, G, D = make(schedule)
+        # reference d_loss for the FIRST iteration: oracle on the same state, scaled by loss_weight_gan
+        torch.manual_seed(11)
+        labels = tr.criterion_gan.draw_labels()
+        d_loss, g_loss = tr.step(x, y, labels=labels)
+        torch.cuda.synchronize()
+        if schedule["type"] == "static":
+            # first-iteration d_loss against the CPU oracle on the same state: loss_weight_gan * 0.5 * (BCE + BCE)
+            from oracle import gan_oracle as o2
+            PG = o3.fill_state(o3.generator3d_spec(c, c, 0, "batch"), 41)
+            PD = o3.fill_state(o3.discriminator3d_spec(c, "batch"), 42)
+            ctx = o3.NormCtx("batch", True)
+            with torch.no_grad():
+                fake = o3.generator3d(PG, x.cpu(), ctx)
+                lr_, _ = o3.discriminator3d(PD, y.cpu(), ctx)
+                lf_, _ = o3.discriminator3d(PD, fake, ctx)
+                lab_fake, lab_real, swap = labels
+                d_ref = 0.5 * o2.gan_d_loss("ModifiedMinMax", lr_, lf_, lab_fake.cpu(), lab_real.cpu(), swap)
+            assert abs(float(d_loss) - float(d_ref)) <= 1e-3 * abs(float(d_ref)), (float(d_loss), float(d_ref))
+        g0, d0 = G.arena().master.clone(), D.arena().master.clone()
+        d_loss, g_loss = tr.step(x, y, labels=labels)     # schedule now sees the first iteration's accuracy
+        torch.cuda.synchronize()
+        assert np.isfinite(float(d_loss)) and np.isfinite(float(g_loss)) and 0.0 <= tr.d_acc_avg <= 1.0
+        assert (not torch.equal(G.arena().master, g0)) == g_moves, schedule
+        assert (not torch.equal(D.arena().master, d0)) == d_moves, schedule
+        # BatchNorm statistics move on every iteration regardless of the schedule (train-mode forwards)
+        assert int(D.state_dict()["xception_features.bn1.num_batches_tracked"]) == 6
