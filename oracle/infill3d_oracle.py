@@ -1,0 +1,143 @@
+"""CPU restatement of the reference's partial-convolution U-Net GAN in 3-D --
+TEST INFRASTRUCTURE ONLY.  Reference files under /root/reference/src/deepCam/: architecture/common/partialconv3d.py,
+architecture/gpsro/infill3d.py (PCBActiv3d, PConvUNet3d), architecture/gpsro/infill3d_gan.py (Discriminator),
+utils/losses.py:40-98 (InpaintingLoss, total_variation_loss), gpsro_train/infill3d_gan_module.py:290-375 (loop).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Pinned against the reference by tests/golden/infill3d_*.npz (tests/golden/make_golden.py, `infill3d` target).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .gan_oracle import NormCtx, State, _norm_entries, fill_state, norm, trainable_keys  # noqa: F401
+
+PC_EPS = 1e-6   # PCBActiv3d builds every PartialConv3d with eps=1e-6 (infill3d.py:86-99)
+
+
+def _enc_channels(i: int, cin: int):
+    """(in, out) channels of enc_i (infill3d.py:143-150)."""
+    table = {1: (cin, 64), 2: (64, 128), 3: (128, 256), 4: (256, 512)}
+    return table.get(i, (512, 512))
+
+
+def _dec_channels(i: int, cin: int):
+    """(in, out) channels of dec_i (infill3d.py:152-158)."""
+    table = {4: (512 + 256, 256), 3: (256 + 128, 128), 2: (128 + 64, 64), 1: (64 + cin, 32)}
+    return table.get(i, (512 + 512, 512))
+
+
+def _pcb_entries(prefix, cin, cout, k, norm_kind, bias=False):
+    s = [(prefix + ".conv.weight", (cout, cin, k, k, k), "conv")]
+    if bias:
+        s.append((prefix + ".conv.bias", (cout,), "bias"))
+    if norm_kind is not None:
+        s += _norm_entries(prefix + ".bn", cout, norm_kind)
+    return s
+
+
+def unet3d_spec(cin: int, cout: int, layer_size: int = 7, norm_kind: str = "batch"):
+    """state_dict entries of PConvUNet3d in registration order (infill3d.py:139-165)."""
+    s = []
+    for i in range(1, max(layer_size, 4) + 1):
+        ci, co = _enc_channels(i, cin)
+        s += _pcb_entries(f"enc_{i}", ci, co, 3, None if i == 1 else norm_kind)
+    for i in range(5, layer_size + 1):
+        ci, co = _dec_channels(i, cin)
+        s += _pcb_entries(f"dec_{i}", ci, co, 3, norm_kind)
+    for i in (4, 3, 2, 1):
+        ci, co = _dec_channels(i, cin)
+        s += _pcb_entries(f"dec_{i}", ci, co, 3, norm_kind)
+    s += _pcb_entries("last_conv", 32, cout, 1, None, bias=True)
+    return s
+
+
+def disc3d_spec(cin: int, layer_size: int = 7, norm_kind: str = "batch"):
+    """state_dict entries of infill3d_gan.Discriminator (infill3d_gan.py:17-30)."""
+    s = []
+    for i in range(1, max(layer_size, 4) + 1):
+        ci, co = _enc_channels(i, cin)
+        s += _pcb_entries(f"enc_{i}", ci, co, 3, None if i == 1 else norm_kind)
+    s.append(("linear.weight", (1, 512), "linear"))
+    return s
+
+
+def partial_conv3d(x, mask, w, b, stride, pad):
+    """PartialConv3d.forward with multi_channel=True, return_mask=True (partialconv3d.py:49-92)."""
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    with torch.no_grad():
+        ones = torch.ones(1, cin, k, k, k, dtype=mask.dtype)
+        upd = F.conv3d(mask, ones, None, stride, pad).expand(-1, cout, -1, -1, -1)   # identical for every output channel
+        ratio = float(cin * k ** 3) / (upd + PC_EPS)
+        upd = torch.clamp(upd, 0, 1)
+        ratio = ratio * upd
+    raw = F.conv3d(x * mask, w, b, stride, pad)
+    if b is not None:
+        bv = b.view(1, -1, 1, 1, 1)
+        out = ((raw - bv) * ratio + bv) * upd
+    else:
+        out = raw * ratio
+    return out, upd
+
+
+def pcb_activ(P: State, key: str, x, mask, k, stride, pad, has_norm, act, ctx: NormCtx):
+    """PCBActiv3d.forward (infill3d.py:108-114): partial conv -> normalizer -> ReLU | LeakyReLU(0.2) | none."""
+    h, m = partial_conv3d(x, mask, P[key + ".conv.weight"], P.get(key + ".conv.bias"), stride, pad)
+    if has_norm:
+        h = norm(P, key + ".bn", h, ctx)
+    if act == "relu":
+        h = F.relu(h)
+    elif act == "leaky":
+        h = F.leaky_relu(h, 0.2)
+    return h, m
+
+
+def unet3d(P: State, x, mask, layer_size: int, ctx: NormCtx):
+    """PConvUNet3d.forward (infill3d.py:177-239), upsampling_mode='nearest', no dropout."""
+    hs, ms = {0: x}, {0: mask}
+    for i in range(1, layer_size + 1):
+        hs[i], ms[i] = pcb_activ(P, f"enc_{i}", hs[i - 1], ms[i - 1], 3, 2, 1, i != 1, "relu", ctx)
+    h, m = hs[layer_size], ms[layer_size]
+    for i in range(layer_size, 0, -1):
+        size = tuple(hs[i - 1].shape[2:])
+        h = F.interpolate(h, size=size, mode="nearest")
+        m = F.interpolate(m, size=size, mode="nearest")
+        h = torch.cat([h, hs[i - 1]], dim=1)
+        m = torch.cat([m, ms[i - 1]], dim=1)
+        h, m = pcb_activ(P, f"dec_{i}", h, m, 3, 1, 1, True, "leaky", ctx)
+    return pcb_activ(P, "last_conv", h, m, 1, 1, 0, False, None, ctx)
+
+
+def disc3d(P: State, x, mask, layer_size: int, ctx: NormCtx):
+    """infill3d_gan.Discriminator.forward (infill3d_gan.py:43-63).  Quirk kept: every enc layer runs, but the
+    logits come from the mean of the output of layer layer_size-1 (`enc_h_key = 'h_{i-1}'` after the loop)."""
+    hs, ms = {0: x}, {0: mask}
+    for i in range(1, layer_size + 1):
+        hs[i], ms[i] = pcb_activ(P, f"enc_{i}", hs[i - 1], ms[i - 1], 3, 2, 1, i != 1, "relu", ctx)
+    feat = hs[layer_size - 1].mean(dim=(2, 3, 4))
+    logits = F.linear(feat, P["linear.weight"])
+    return logits, torch.sigmoid(logits)
+
+
+def total_variation_loss(image):
+    """utils/losses.py:40-44, applied as written to a 5-D tensor: shifts along dims 3 and 2."""
+    return (image[:, :, :, :-1] - image[:, :, :, 1:]).abs().mean() + (image[:, :, :-1, :] - image[:, :, 1:, :]).abs().mean()
+
+
+def inpainting_loss(inp, out, gt, mask, loss_type: str = "smooth-l1"):
+    """InpaintingLoss.forward without a feature extractor (utils/losses.py:62-98) -> {'hole','valid','tv'}."""
+    dist = {"l1": F.l1_loss, "smooth-l1": F.smooth_l1_loss, "l2": F.mse_loss}[loss_type]
+    comp = mask * inp + (1 - mask) * out
+    return {"hole": dist((1. - mask) * out, (1. - mask) * gt), "valid": dist(mask * out, mask * gt),
+            "tv": total_variation_loss(comp)}
+
+
+def synthetic_infill(n, c, d, h, w, seed, hole=0.3):
+    """(input with holes zeroed, ground truth, 0/1 mask per channel)."""
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.randn((n, c, d, h, w), generator=g)
+    mask = (torch.rand((n, c, d, h, w), generator=g) > hole).float()
+    return gt * mask, gt, mask

@@ -27,6 +27,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/src/deepCam")
 sys.modules.setdefault("conv2d_local", types.ModuleType("conv2d_local"))
+# architecture/gpsro/infill3d.py:8 and infill3d_gan.py:8 import `models` from torchvision (absent here) and never
+# use it: an empty module object in its place, as for conv2d_local
+if "torchvision" not in sys.modules:
+    _tv = types.ModuleType("torchvision")
+    _tv.models = types.ModuleType("torchvision.models")
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = _tv, _tv.models
 sys.dont_write_bytecode = True
 
 from architecture.gpsro import deeplab as ref_dl  # noqa: E402
@@ -36,6 +42,9 @@ from architecture.gpsro import deeplab3d_gan as ref_gan3d  # noqa: E402
 
 from oracle import gan_oracle as orc  # noqa: E402  (only for specs / deterministic fills / fields)
 from oracle import gan3d_oracle as orc3  # noqa: E402
+from oracle import infill3d_oracle as orci  # noqa: E402
+sys.path.insert(0, "/root/reference/src/deepCam/architecture/gpsro")
+from architecture.gpsro import infill3d_gan as ref_infill  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -427,8 +436,59 @@ def golden_gan3d(c=1, d=16, h=24, w=24, n=2):
     print("gan3d goldens written: g loss", float(res["g::loss"]), "gp", float(res["gp::value"]))
 
 
+def golden_infill3d(cin=2, cout=1, d=16, h=16, w=16, n=2, g_layers=4, d_layers=5):
+    """Partial-convolution U-Net generator and discriminator in 3-D + the inpainting loss."""
+    res = {}
+    g = ref_infill.Generator(layer_size=g_layers, input_channels=cin, output_channels=cout, upsampling_mode="nearest",
+                             normalizer=nn.BatchNorm3d)
+    gspec = orci.unet3d_spec(cin, cout, g_layers)
+    _load_checked(g, gspec, 51)
+    g.train()
+    x, gt, mask = orci.synthetic_infill(n, cin, d, h, w, 151)
+    out, out_mask = g(x, mask)
+    ld = ref_losses.InpaintingLoss(loss_type="smooth-l1")(x[:, :cout], out, gt[:, :cout], mask[:, :cout])
+    loss = 6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]
+    loss.backward()
+    res["g::out"], res["g::out_mask"] = out.detach().numpy(), out_mask.detach().numpy()
+    for k_ in ("hole", "valid", "tv"):
+        res["g::loss_" + k_] = np.array(ld[k_].item())
+    cs = checksums((k, p.grad) for k, p in g.named_parameters())
+    res["g::grad_keys"], res["g::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+    named = dict(g.named_parameters())
+    for k in ("enc_1.conv.weight", "enc_2.bn.weight", "dec_1.conv.weight", "dec_3.bn.bias", "last_conv.conv.weight",
+              "last_conv.conv.bias"):
+        res["g::grad::" + k] = named[k].grad.numpy()
+    sd = g.state_dict()
+    for k in ("enc_2.bn.running_mean", "dec_1.bn.running_var"):
+        res["g::buf::" + k] = sd[k].numpy()
+    # intermediate masks of the encoder (bit-exact index/mask arithmetic)
+    with torch.no_grad():
+        m_ = mask
+        for i in range(1, g_layers + 1):
+            _, m_ = getattr(g, f"enc_{i}").conv(torch.zeros_like(m_), m_)
+            res[f"g::enc_mask_{i}"] = m_[:, :1].numpy()
+    dm = ref_infill.Discriminator(layer_size=d_layers, input_channels=cout, normalizer=nn.BatchNorm3d)
+    dspec = orci.disc3d_spec(cout, d_layers)
+    _load_checked(dm, dspec, 52)
+    dm.train()
+    xd = gt[:, :cout].clone().requires_grad_(True)
+    logits, pred = dm(xd, mask[:, :cout])
+    tgt = torch.linspace(0.1, 0.9, n).reshape(-1, 1)
+    dl = nn.functional.binary_cross_entropy_with_logits(logits, tgt)
+    dl.backward()
+    res["d::logits"], res["d::loss"], res["d::dx"] = logits.detach().numpy(), np.array(dl.item()), xd.grad.numpy()
+    cs = checksums((k, p.grad) for k, p in dm.named_parameters() if p.grad is not None)
+    res["d::grad_keys"], res["d::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+    np.savez_compressed(os.path.join(HERE, "infill3d_c2_16x16x16.npz"),
+                        meta=json.dumps(dict(cin=cin, cout=cout, d=d, h=h, w=w, n=n, g_layers=g_layers, d_layers=d_layers,
+                                             g_seed=51, d_seed=52, field_seed=151)), **res)
+    print("infill3d goldens written:", {k_: float(res["g::loss_" + k_]) for k_ in ("hole", "valid", "tv")})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
+    if "all" in which or "infill3d" in which:
+        golden_infill3d()
     if "all" in which or "gan3d" in which:
         golden_gan3d()
     if "all" in which or "keys" in which:
