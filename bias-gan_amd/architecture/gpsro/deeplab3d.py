@@ -52,8 +52,9 @@ class Conv3d(BGModule):
             nn.init.uniform_(self.bias, -bound, bound)
         self._bg_param_layout = {"weight": _dw3d_layout if groups > 1 else _conv3d_layout, "bias": _vec_layout}
 
-    def forward(self, x, n, stats=None):
-        """x: [N*D, H, W, Cin] folded volume; returns [N*Do, Ho, Wo, Cout]."""
+    def forward(self, x, n, stats=None, with_bias=True):
+        """x: [N*D, H, W, Cin] folded volume; returns [N*Do, Ho, Wo, Cout].  with_bias=False leaves the bias to the
+        caller (the partial convolution adds it after its mask ratio)."""
         a = self.arena()
         ws = a.by_param[id(self.weight)]
         k, s, p, d = self.kernel_size[0], self.stride[0], self.padding[0], self.dilation[0]
@@ -62,8 +63,9 @@ class Conv3d(BGModule):
             return ops.DwConv3dFn.apply(x, self.weight, a, ws, n, s, d)
         if k > 1 or s > 1:   # gather the depth taps (k = 1, stride 2: depth subsampling) next to the channels
             x = ops.DepthUnfoldFn.apply(x, n, k, s, p, d)
-        bs = None if self.bias is None else a.by_param[id(self.bias)]
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, bs, s, p, d, stats)
+        if self.bias is None or not with_bias:
+            return ops.Conv2dFn.apply(x, self.weight, None, a, ws, None, s, p, d, stats)
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, a.by_param[id(self.bias)], s, p, d, stats)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size[0]}, s={self.stride[0]}, groups={self.groups}"

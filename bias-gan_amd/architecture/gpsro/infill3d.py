@@ -1,0 +1,123 @@
+"""Partial-convolution U-Net in 3-D on the MI355X kernels.
+
+Host-side mirror of the reference's ``architecture/gpsro/infill3d.py`` (PCBActiv3d, PConvUNet3d) and
+``architecture/common/partialconv3d.py`` (PartialConv3d with multi_channel=True, return_mask=True): same class
+names, constructor arguments and state_dict keys.  Volumes and masks live as folded NHWC tensors [N*D,H,W,C]
+(see deeplab3d.py); masks hold exact 0/1 values in the compute dtype.
+
+PartialConv3d = mask window sum (bg_mask_window) + input*mask (bg_mul_rows) + the dense convolution (depth unfold +
+2-D GEMM kernels, deeplab3d.Conv3d) + raw_out*mask_ratio (bg_scale_rows); the updated mask is clamp(window sum, 0, 1)
+broadcast over the output channels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...runtime import BGModule, pad_to, vec_of
+from .deeplab3d import Conv3d, apply_norm3d, from_folded, to_folded
+
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+
+class PartialConv3d(Conv3d):
+    """nn.Conv3d subclass of the reference (partialconv3d.py:14-92) for multi_channel=True, return_mask=True."""
+
+    def __init__(self, *args, multi_channel=True, return_mask=True, eps=1.e-8, **kwargs):
+        if not (multi_channel and return_mask):
+            raise NotImplementedError("only PartialConv3d(multi_channel=True, return_mask=True) occurs on this path")
+        super().__init__(*args, **kwargs)
+        self.multi_channel, self.return_mask, self.eps = True, True, eps
+
+    def forward(self, x, mask, n):
+        """x, mask: folded [N*D,H,W,Cin]; returns (output [N*Do,Ho,Wo,Cout], update_mask of the same shape).
+        partialconv3d.py:79-84: ((conv + b - b) * ratio + b) * update_mask = conv * ratio + b * update_mask, since
+        ratio already carries the 0/1 update_mask factor."""
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        upd, ratio, (do, ho, wo) = ops.mask_window(mask, n, k, s, p, self.eps, self.in_channels)
+        raw = super().forward(ops.MulRowsFn.apply(x, mask), n, with_bias=False)
+        a = self.arena()
+        bs = None if self.bias is None else a.by_param[id(self.bias)]
+        out = ops.ScaleRowsFn.apply(raw, ratio, self.bias, upd if bs is not None else None, a, bs)
+        new_mask = ops.rows_from_scalar(upd, n * do, ho, wo, raw.shape[3], raw.dtype)
+        return out, new_mask
+
+
+class PCBActiv3d(BGModule):
+    """PartialConv3d -> normalizer -> ReLU | LeakyReLU(0.2) | none (infill3d.py:82-114)."""
+
+    def __init__(self, in_ch, out_ch, normalizer=nn.BatchNorm3d, sample='none-3', activ='relu', conv_bias=False):
+        super().__init__()
+        k, s, p = {'down-5': (5, 2, 2), 'down-7': (7, 2, 3), 'down-3': (3, 2, 1), 'point-1': (1, 1, 0)}.get(sample, (3, 1, 1))
+        self.conv = PartialConv3d(in_ch, out_ch, k, s, p, bias=conv_bias, multi_channel=True, return_mask=True, eps=1e-6)
+        if normalizer is not None:
+            self.bn = normalizer(out_ch)
+        if activ == 'relu':
+            self.activation = nn.ReLU()
+        elif activ == 'leaky':
+            self.activation = nn.LeakyReLU(negative_slope=0.2)
+
+    def forward(self, x, mask, n):
+        h, m = self.conv(x, mask, n)
+        act = ACT_NONE
+        if hasattr(self, 'activation'):
+            act = ACT_RELU if isinstance(self.activation, nn.ReLU) else ACT_LEAKY
+        if hasattr(self, 'bn'):
+            h = apply_norm3d(self, self.bn, h, n, act=act)
+        elif act:
+            h = ops.NormActFn.apply(h, None, None, None, None, None, None, None, None, "identity", False, act, 0.0, 0.0)
+        return h, m
+
+
+class PConvUNet3d(BGModule):
+    """Partial-convolution U-Net (infill3d.py:135-239), upsampling_mode='nearest', dropout_p = 0."""
+
+    def __init__(self, layer_size=7, input_channels=3, output_channels=3, upsampling_mode='nearest',
+                 normalizer=nn.BatchNorm3d, dropout_p=0., compute_dtype=None):
+        super().__init__()
+        if upsampling_mode != 'nearest' or dropout_p > 0.:
+            raise NotImplementedError("the HIP path builds upsampling_mode='nearest' without dropout")
+        self.freeze_enc_bn = False
+        self.upsampling_mode, self.layer_size = upsampling_mode, layer_size
+        self.input_channels, self.output_channels = input_channels, output_channels
+        self.enc_1 = PCBActiv3d(input_channels, 64, sample='down-3', normalizer=None)
+        self.enc_2 = PCBActiv3d(64, 128, sample='down-3', normalizer=normalizer)
+        self.enc_3 = PCBActiv3d(128, 256, sample='down-3', normalizer=normalizer)
+        self.enc_4 = PCBActiv3d(256, 512, sample='down-3', normalizer=normalizer)
+        for i in range(4, self.layer_size):
+            setattr(self, 'enc_{:d}'.format(i + 1), PCBActiv3d(512, 512, sample='down-3', normalizer=normalizer))
+        for i in range(4, self.layer_size):
+            setattr(self, 'dec_{:d}'.format(i + 1), PCBActiv3d(512 + 512, 512, activ='leaky', normalizer=normalizer))
+        self.dec_4 = PCBActiv3d(512 + 256, 256, activ='leaky', normalizer=normalizer)
+        self.dec_3 = PCBActiv3d(256 + 128, 128, activ='leaky', normalizer=normalizer)
+        self.dec_2 = PCBActiv3d(128 + 64, 64, activ='leaky', normalizer=normalizer)
+        self.dec_1 = PCBActiv3d(64 + input_channels, 32, activ='leaky', normalizer=normalizer)
+        self.dropout = None
+        self.last_conv = PCBActiv3d(32, output_channels, activ=None, normalizer=None, sample='point-1', conv_bias=True)
+        for m in self.modules():    # __init_weights (infill3d.py:166-175): kaiming_normal_ convs, zero biases
+            if isinstance(m, Conv3d):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        if compute_dtype is not None:
+            self.set_compute_dtype(compute_dtype)
+
+    def forward(self, input, input_mask):
+        """NCDHW fp32 input and 0/1 mask [N,Cin,D,H,W] -> (output [N,Cout,D,H,W] fp32, its mask)."""
+        dt = self.compute_dtype()
+        n, c = input.shape[0], input.shape[1]
+        cp = pad_to(c, vec_of(dt))
+        hs, ms = {0: to_folded(input, cp, dt)}, {0: to_folded(input_mask, cp, dt)}
+        for i in range(1, self.layer_size + 1):
+            hs[i], ms[i] = getattr(self, 'enc_{:d}'.format(i))(hs[i - 1], ms[i - 1], n)
+        h, m = hs[self.layer_size], ms[self.layer_size]
+        for i in range(self.layer_size, 0, -1):
+            e, em = hs[i - 1], ms[i - 1]
+            size = (e.shape[0] // n, e.shape[1], e.shape[2])
+            h = ops.NearestResize3dFn.apply(h, n, *size)
+            m = ops.NearestResize3dFn.apply(m, n, *size)
+            h, m = ops.concat(h, e), ops.concat(m, em)
+            h, m = getattr(self, 'dec_{:d}'.format(i))(h, m, n)
+        h, m = self.last_conv(h, m, n)
+        return from_folded(h, n, self.output_channels), from_folded(m, n, self.output_channels)

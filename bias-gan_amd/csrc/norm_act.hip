@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float gg = va.get(e);
-                    if (P.act) gg *= ((b ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : LRELU_SLOPE);
+                    if (P.act) gg *= ((b ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : act_slope(P.act));
                     s1[e] += gg;
                     if (cc) s2[e] = fmaf(gg, (vx.get(e) - mu[e]) * rs[e], s2[e]);
                 }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
         for (int e = 0; e < VEC; ++e) {
             float z = fmaf(vx.get(e), sc[e], sh[e]);
             if (res) z += vr.get(e);
-            if (P.act) z = lrelu_f(z);
+            if (P.act) z = z >= 0.f ? z : act_slope(P.act) * z;
             vo.set(e, z);
         }
         vo.store(y);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             gg[e] = vg.get(e);
-            if (P.act) gg[e] *= ((y ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : LRELU_SLOPE);
+            if (P.act) gg[e] *= ((y ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : act_slope(P.act));
         }
         if (dres) {
 #pragma unroll

@@ -695,6 +695,136 @@ def resize_trilinear(x, n, do, ho, wo, out_dtype=None):
     return ResizeBilinearFn.apply(x, ho, wo, out_dtype)
 
 
+# ------------------------------------------------------------- partial convolution (row (f)-4)
+def mask_window(mask, n, k, stride, pad, eps, channels=None):
+    """Mask half of PartialConv3d on a folded mask [N*D,H,W,C] (exact 0/1 values): returns
+    (update_mask, mask_ratio) as fp32 [N*Do*Ho*Wo] vectors and the output dims.  No gradient (constants).
+    channels: the layer's in_channels when the folded tensor carries pad lanes (they are not counted)."""
+    mask = nhwc(mask)
+    nd, h, w, c = mask.shape
+    c = c if channels is None else channels
+    d = nd // n
+    do, ho, wo = ((x + 2 * pad - k) // stride + 1 for x in (d, h, w))
+    upd = torch.empty(n * do * ho * wo, dtype=torch.float32, device=mask.device)
+    ratio = torch.empty_like(upd)
+    L.call("bg_mask_window", L.dt(mask.dtype), mask.data_ptr(), ld_of(mask), c, n, d, h, w, do, ho, wo, k, stride, pad, float(eps),
+           upd.data_ptr(), ratio.data_ptr())
+    return upd, ratio, (do, ho, wo)
+
+
+def rows_from_scalar(s, n_slices, h, w, c, dtype):
+    """[rows] fp32 -> folded tensor [n_slices,h,w,c] with every channel equal to s[row] (the Cout identical
+    channels of PartialConv3d's update_mask)."""
+    y = new_act(n_slices, h, w, c, dtype, s.device)
+    L.call("bg_scale_rows", L.dt(dtype), None, 0, s.data_ptr(), None, None, y.data_ptr(), ld_of(y), n_slices * h * w, c)
+    return y
+
+
+class MulRowsFn(torch.autograd.Function):
+    """y = x * m, m a constant tensor of the same folded shape (input * mask_in, partialconv3d.py:77)."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        x, m = nhwc(x), nhwc(m)
+        n, h, w, c = x.shape
+        y = new_act(n, h, w, c, x.dtype, x.device)
+        L.call("bg_mul_rows", L.dt(x.dtype), x.data_ptr(), ld_of(x), m.data_ptr(), ld_of(m), y.data_ptr(), ld_of(y), n * h * w, c)
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = nhwc(g)
+        n, h, w, c = g.shape
+        dx = new_act(n, h, w, c, g.dtype, g.device)
+        L.call("bg_mul_rows", L.dt(g.dtype), g.data_ptr(), ld_of(g), m.data_ptr(), ld_of(m), dx.data_ptr(), ld_of(dx), n * h * w, c)
+        return dx, None
+
+
+class ScaleRowsFn(torch.autograd.Function):
+    """y[r,c] = x[r,c] * s[r] (+ bias[c] * t[r]): raw_out * mask_ratio, and the bias form of partialconv3d.py:79-84."""
+
+    @staticmethod
+    def forward(ctx, x, s, bias, t, arena, bslot):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        y = new_act(n, h, w, c, x.dtype, x.device)
+        L.call("bg_scale_rows", L.dt(x.dtype), x.data_ptr(), ld_of(x), s.data_ptr(), None if bslot is None else arena.master_ptr(bslot),
+               L.ptr(t), y.data_ptr(), ld_of(y), n * h * w, c)
+        ctx.save_for_backward(s, t)
+        ctx.meta = (arena, bslot)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t = ctx.saved_tensors
+        arena, bslot = ctx.meta
+        g = nhwc(g)
+        n, h, w, c = g.shape
+        rows = n * h * w
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_act(n, h, w, c, g.dtype, g.device)
+            L.call("bg_scale_rows", L.dt(g.dtype), g.data_ptr(), ld_of(g), s.data_ptr(), None, None, dx.data_ptr(), ld_of(dx), rows, c)
+        if bslot is not None and ctx.needs_input_grad[2]:
+            arena.ensure_grad(bslot)
+            tmp = new_act(n, h, w, c, g.dtype, g.device)
+            L.call("bg_scale_rows", L.dt(g.dtype), g.data_ptr(), ld_of(g), t.data_ptr(), None, None, tmp.data_ptr(), ld_of(tmp), rows, c)
+            L.call("bg_colsum", L.dt(g.dtype), tmp.data_ptr(), ld_of(tmp), rows, c, 1, 1.0, arena.grad_ptr(bslot))
+        return dx, None, None, None, None, None
+
+
+class NearestResize3dFn(torch.autograd.Function):
+    """F.interpolate(size=(do,ho,wo), mode='nearest') on a folded volume (infill3d.py:217-222)."""
+
+    @staticmethod
+    def forward(ctx, x, n, do, ho, wo):
+        x = nhwc(x)
+        nd, hi, wi, c = x.shape
+        di = nd // n
+        y = new_act(n * do, ho, wo, c, x.dtype, x.device)
+        L.call("bg_resize_nearest3d_fwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, di, hi, wi, do, ho, wo, c)
+        ctx.meta = (n, di, hi, wi, do, ho, wo, c, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, di, hi, wi, do, ho, wo, c, dtype = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n * di, hi, wi, c, dtype, g.device)
+        L.call("bg_resize_nearest3d_bwd", L.dt(dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, di, hi, wi, do, ho, wo, c)
+        return dx, None, None, None, None
+
+
+class TVLossCompFn(torch.autograd.Function):
+    """total_variation_loss(mask*input + (1-mask)*output) of InpaintingLoss (utils/losses.py:40-44,71,97) on
+    contiguous fp32 [N,C,D,H,W] tensors; differentiable w.r.t. `output`."""
+
+    @staticmethod
+    def forward(ctx, output, inp, mask):
+        o, i_, m = (t.contiguous().float() for t in (output, inp, mask))
+        n, c, d, h, w = o.shape
+        comp = torch.empty_like(o)
+        L.call("bg_blend_f32", m.data_ptr(), i_.data_ptr(), o.data_ptr(), comp.data_ptr(), o.numel())
+        loss = _f32(1, device=o.device)
+        L.call("bg_tv_loss_fwd", comp.data_ptr(), n * c, d, h, w, loss.data_ptr())
+        ctx.save_for_backward(comp, m)
+        ctx.dims = (n * c, d, h, w)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        comp, m = ctx.saved_tensors
+        a, d, h, w = ctx.dims
+        coef = g.reshape(1).float().contiguous()
+        dcomp = torch.empty_like(comp)
+        L.call("bg_tv_loss_bwd", comp.data_ptr(), a, d, h, w, coef.data_ptr(), dcomp.data_ptr())
+        dout = torch.empty_like(comp)
+        L.call("bg_blend_f32", m.data_ptr(), None, dcomp.data_ptr(), dout.data_ptr(), comp.numel())   # (1 - m) * dcomp
+        return dout, None, None
+
+
 # ---------------------------------------------------------------------------- head
 class LinearHeadFn(torch.autograd.Function):
     """reshape(N,-1) + nn.Linear(F,1) on the NCHW-ordered features (deeplab_gan.py:32-35)."""
@@ -726,6 +856,38 @@ class LinearHeadFn(torch.autograd.Function):
         L.call("bg_linear_head_bwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), arena.master_ptr(wslot), g.data_ptr(), L.ptr(dx),
                0 if dx is None else ld_of(dx), dw, db, n, h * w, c)
         return dx, None, None, None, None, None
+
+
+class LinearHeadNoBiasFn(torch.autograd.Function):
+    """nn.Linear(F, 1, bias=False) on pooled features (infill3d_gan.py:30,61-62); `zero_bias`: a device zero."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, zero_bias):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        assert wslot.numel == c * h * w
+        logits = _f32(n, 1, device=x.device)
+        L.call("bg_linear_head_fwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), arena.master_ptr(wslot), zero_bias.data_ptr(),
+               logits.data_ptr(), n, h * w, c)
+        ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        arena, wslot = ctx.meta
+        n, h, w, c = x.shape
+        g = g.contiguous().float()
+        dx = new_act(n, h, w, c, x.dtype, x.device) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            arena.ensure_grad(wslot)
+            dw = arena.grad_ptr(wslot)
+        if dx is not None or dw is not None:
+            L.call("bg_linear_head_bwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), arena.master_ptr(wslot), g.data_ptr(), L.ptr(dx),
+                   0 if dx is None else ld_of(dx), dw, None, n, h * w, c)
+        return dx, None, None, None, None
 
 
 # -------------------------------------------------------------------------- losses

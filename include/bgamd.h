@@ -148,6 +148,41 @@ int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int3
                         int32_t Di, int32_t Do, int32_t HW, int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Partial-convolution U-Net GAN (architecture/common/partialconv3d.py,
+ * architecture/gpsro/infill3d.py, infill3d_gan.py).  Volumes and masks are folded NHWC tensors [N*D,H,W,C];
+ * masks hold exact 0/1 values.
+ *
+ * bg_mask_window: the mask half of PartialConv3d(multi_channel=True) (partialconv3d.py:49-75): s = sum of the mask
+ *   over all C input channels and the k^3 window ("conv with all-ones weights"; the same for every output
+ *   channel), update_mask = clamp(s, 0, 1), ratio = C*k^3 / (s + eps) * update_mask; both fp32 [N*Do*Ho*Wo].
+ *   C is the layer's real channel count (pad lanes up to the next vector multiple are ignored).
+ * bg_mul_rows:   y = x * m (element-wise; input * mask_in, partialconv3d.py:77).
+ * bg_scale_rows: y[r,c] = (x ? x[r,c] : 1) * s[r] + (bias ? bias[c] * t[r] : 0): raw_out * mask_ratio, the bias form
+ *   ((raw - b) * ratio + b) * update_mask = conv_nobias * ratio + b * update_mask (ratio already carries the
+ *   update_mask factor), and -- with x == NULL -- the broadcast of update_mask to the Cout mask channels.
+ *   Both are their own adjoints w.r.t. x.
+ * bg_resize_nearest3d_*: F.interpolate(size=..., mode='nearest') (infill3d.py:217-222), source index
+ *   floor(dst * in / out); _bwd is the adjoint (overwrites dx).
+ * bg_tv_loss_*: total_variation_loss (utils/losses.py:40-44) as it acts on a contiguous fp32 5-D tensor viewed as
+ *   [A][D][H][W]: mean |shift along H| + mean |shift along D|; loss accumulated (caller zeroes), dx = coef[0] * d loss/dx.
+ * ------------------------------------------------------------------------- */
+int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, int32_t N, int32_t D, int32_t H, int32_t W,
+                   int32_t Do, int32_t Ho, int32_t Wo, int32_t k, int32_t stride, int32_t pad, float eps, float* update_mask,
+                   float* ratio, void* stream);
+int bg_mul_rows(int32_t dtype, const void* x, int32_t ldx, const void* m, int32_t ldm, void* y, int32_t ldy, int64_t rows,
+                int32_t C, void* stream);
+int bg_scale_rows(int32_t dtype, const void* x, int32_t ldx, const float* s, const float* bias, const float* t, void* y,
+                  int32_t ldy, int64_t rows, int32_t C, void* stream);
+int bg_resize_nearest3d_fwd(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Di, int32_t Hi,
+                            int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int bg_resize_nearest3d_bwd(int32_t dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N, int32_t Di,
+                            int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+/* y = m*a + (1-m)*b on flat fp32 arrays (output_comp, utils/losses.py:71); a == NULL: y = (1-m)*b (its adjoint w.r.t. b). */
+int bg_blend_f32(const float* m, const float* a, const float* b, float* y, int64_t n, void* stream);
+int bg_tv_loss_fwd(const float* x, int64_t A, int32_t D, int32_t H, int32_t W, float* loss, void* stream);
+int bg_tv_loss_bwd(const float* x, int64_t A, int32_t D, int32_t H, int32_t W, const float* coef, float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Normalisation (BatchNorm2d train/eval, InstanceNorm2d, Identity) fused with
  * the residual add (Block: x += skip, deeplab.py:141) and LeakyReLU(0.2)
  * (deeplab.py:100,180,334,365).
@@ -170,7 +205,7 @@ int bg_norm_finalize(const double* sum, const double* sumsq, int64_t rows_per_gr
 int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift, void* stream);
 /* y = act( x*scale[g,c] + shift[g,c] + res ), scale/shift NULL = identity, res
- * NULL = none, act: 0 none, 1 LeakyReLU(0.2).  y may alias x or res. */
+ * NULL = none, act: 0 none, 1 LeakyReLU(0.2), 2 ReLU (every act argument below).  y may alias x or res. */
 int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
                     const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows, int32_t C, int32_t groups,
                     int32_t act, void* stream);

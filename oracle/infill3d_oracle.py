@@ -141,3 +141,88 @@ def synthetic_infill(n, c, d, h, w, seed, hole=0.3):
     gt = torch.randn((n, c, d, h, w), generator=g)
     mask = (torch.rand((n, c, d, h, w), generator=g) > hole).float()
     return gt * mask, gt, mask
+
+
+def infill_update_flags(step: int, warmup: int, d_acc_avg: float, acc_min: float, acc_max: float):
+    """(train_generator, train_discriminator) of infill3d_gan_module.py:294-311."""
+    if step < warmup:
+        return True, False
+    if d_acc_avg > acc_max:       # discriminator too good
+        return True, False
+    if d_acc_avg < acc_min:       # discriminator too bad
+        return False, True
+    return True, True
+
+
+class InfillGANStep:
+    """One iteration of infill3d_gan_module.py:272-375 with the results-neutral waste removed (the D part does not
+    back-propagate into the generator; the G part keeps no discriminator weight gradients).  Every forward runs in
+    train mode -- two generator and three discriminator passes per iteration, whatever the update flags say -- so
+    the BatchNorm running statistics move exactly as in the reference.  The discriminator sees the 1-channel
+    volume against the (1 + noise)-channel mask: `input * mask` broadcasts it (partialconv3d.py:77)."""
+
+    def __init__(self, PG: State, PD: State, g_keys, d_keys, g_layers: int, d_layers: int, loss_weights: dict,
+                 loss_type="smooth-l1", warmup=0, acc_min=0.0, acc_max=1.0, lr_g=1e-4, lr_d=1e-4, eps=1e-8,
+                 weight_decay=1e-5, norm_kind="batch", decoupled=False):
+        from .gan_oracle import Adam
+        self.PG, self.PD, self.g_keys, self.d_keys = PG, PD, g_keys, d_keys
+        self.g_layers, self.d_layers = g_layers, d_layers
+        self.w, self.loss_type = dict(loss_weights), loss_type
+        self.warmup, self.acc_min, self.acc_max = warmup, acc_min, acc_max
+        self.ctx = NormCtx(norm_kind, True)
+        self.g_opt = Adam(g_keys, lr_g, eps, weight_decay, decoupled=decoupled)     # decoupled: torch.optim.AdamW
+        self.d_opt = Adam(d_keys, lr_d, eps, weight_decay, decoupled=decoupled)
+        self.step_count, self.d_acc_avg = 0, 0.5
+        self.last_flags = (True, True)
+        self.last_terms = {}
+
+    @staticmethod
+    def _leaves(P, keys):
+        Q = dict(P)
+        for k in keys:
+            Q[k] = P[k].detach().requires_grad_(True)
+        return Q
+
+    @staticmethod
+    def _sync_buffers(Q, P):
+        for k in P:
+            if Q[k] is not P[k] and not Q[k].requires_grad:
+                P[k] = Q[k]
+
+    def step(self, inputs_raw, outputs_real, masks_raw, noise, labels):
+        """inputs_raw, outputs_real, masks_raw: [N,1,D,H,W]; noise [N,nd,D,H,W]; labels = draw_d_labels(N)."""
+        from .gan_oracle import gan_d_loss, gan_g_loss
+        inputs = torch.cat((inputs_raw, noise), dim=1)
+        masks = torch.cat((masks_raw, torch.ones_like(noise)), dim=1)
+        train_g, train_d = infill_update_flags(self.step_count, self.warmup, self.d_acc_avg, self.acc_min, self.acc_max)
+        self.last_flags = (train_g, train_d)
+        # ---- discriminator part (:314-341)
+        with torch.no_grad():
+            fake, _ = unet3d(self.PG, inputs, masks, self.g_layers, self.ctx)
+        Q = self._leaves(self.PD, self.d_keys)
+        with torch.set_grad_enabled(train_d):
+            lr_, _ = disc3d(Q, outputs_real, masks, self.d_layers, self.ctx)
+            lf_, _ = disc3d(Q, fake, masks, self.d_layers, self.ctx)
+            lab_f, lab_r, swap = labels
+            d_loss = gan_d_loss("ModifiedMinMax", lr_, lf_, lab_f, lab_r, swap) * self.w["adv"]
+        self.d_acc_avg = float(0.5 * ((lr_ > 0).float().mean() + (lf_ <= 0).float().mean()))
+        self._sync_buffers(Q, self.PD)
+        if train_d:
+            grads = torch.autograd.grad(d_loss, [Q[k] for k in self.d_keys], allow_unused=True)
+            self.d_opt.step(self.PD, {k: g for k, g in zip(self.d_keys, grads) if g is not None})
+        # ---- generator part (:344-373)
+        Q = self._leaves(self.PG, self.g_keys)
+        with torch.set_grad_enabled(train_g):
+            fake, _ = unet3d(Q, inputs, masks, self.g_layers, self.ctx)
+            lf_, _ = disc3d(self.PD, fake, masks, self.d_layers, self.ctx)
+            terms = inpainting_loss(inputs_raw, fake, outputs_real, masks_raw, self.loss_type)
+            if self.step_count >= self.warmup:
+                terms["adv"] = gan_g_loss("ModifiedMinMax", lf_)
+            g_loss = sum(terms[k] * self.w[k] for k in terms)
+        self._sync_buffers(Q, self.PG)
+        if train_g:
+            grads = torch.autograd.grad(g_loss, [Q[k] for k in self.g_keys], allow_unused=True)
+            self.g_opt.step(self.PG, {k: g for k, g in zip(self.g_keys, grads) if g is not None})
+        self.last_terms = {k: float(v.detach()) for k, v in terms.items()}
+        self.step_count += 1
+        return float(d_loss.detach()), float(g_loss.detach())

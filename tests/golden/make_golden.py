@@ -436,7 +436,7 @@ def golden_gan3d(c=1, d=16, h=24, w=24, n=2):
     print("gan3d goldens written: g loss", float(res["g::loss"]), "gp", float(res["gp::value"]))
 
 
-def golden_infill3d(cin=2, cout=1, d=16, h=16, w=16, n=2, g_layers=4, d_layers=5):
+def golden_infill3d(cin=2, cout=1, d=32, h=24, w=40, n=2, g_layers=4, d_layers=5):
     """Partial-convolution U-Net generator and discriminator in 3-D + the inpainting loss."""
     res = {}
     g = ref_infill.Generator(layer_size=g_layers, input_channels=cin, output_channels=cout, upsampling_mode="nearest",
@@ -479,16 +479,101 @@ def golden_infill3d(cin=2, cout=1, d=16, h=16, w=16, n=2, g_layers=4, d_layers=5
     res["d::logits"], res["d::loss"], res["d::dx"] = logits.detach().numpy(), np.array(dl.item()), xd.grad.numpy()
     cs = checksums((k, p.grad) for k, p in dm.named_parameters() if p.grad is not None)
     res["d::grad_keys"], res["d::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
-    np.savez_compressed(os.path.join(HERE, "infill3d_c2_16x16x16.npz"),
+    np.savez_compressed(os.path.join(HERE, f"infill3d_c{cin}_{d}x{h}x{w}.npz"),
                         meta=json.dumps(dict(cin=cin, cout=cout, d=d, h=h, w=w, n=n, g_layers=g_layers, d_layers=d_layers,
                                              g_seed=51, d_seed=52, field_seed=151)), **res)
     print("infill3d goldens written:", {k_: float(res["g::loss_" + k_]) for k_ in ("hole", "valid", "tv")})
+
+
+def golden_infill_trajectory(d=32, h=24, w=40, n=2, g_layers=4, d_layers=5, steps=7, warmup=1, acc_min=0.55, acc_max=0.8,
+                             lr=1e-3, wd=0.01, adam_eps=1e-4):
+    """Seven iterations of the loop body infill3d_gan_module.py:272-375 driven on the reference's Generator,
+    Discriminator, InpaintingLoss, GANLoss and metrics.accuracy with torch.optim.AdamW (the optimizer / weights /
+    thresholds of gpsro_configs/infill3d_gan_1.yaml, lr 1e-3, tv weight 0.1 so that every term acts)."""
+    from utils import metrics as ref_metrics
+    weights = {"valid": 1.0, "hole": 0.5, "tv": 0.1, "adv": 0.5}
+    nd = 1
+    g = ref_infill.Generator(layer_size=g_layers, input_channels=1 + nd, output_channels=1, upsampling_mode="nearest",
+                             normalizer=nn.BatchNorm3d)
+    dm = ref_infill.Discriminator(layer_size=d_layers, input_channels=1 + nd, normalizer=nn.BatchNorm3d)
+    gspec, dspec = orci.unet3d_spec(1 + nd, 1, g_layers), orci.disc3d_spec(1 + nd, d_layers)
+    _load_checked(g, gspec, 61)
+    _load_checked(dm, dspec, 62)
+    g.train(); dm.train()
+    g_opt = torch.optim.AdamW(g.parameters(), lr=lr, eps=adam_eps, weight_decay=wd)
+    d_opt = torch.optim.AdamW(dm.parameters(), lr=lr, eps=adam_eps, weight_decay=wd)
+    crit = ref_losses.GANLoss("ModifiedMinMax", n, torch.device("cpu"))
+    rec = ref_losses.InpaintingLoss(loss_type="l2")
+    torch.manual_seed(444)
+    res = {k: [] for k in ("d_loss", "g_loss", "d_acc", "train_g", "train_d", "labels_fake", "labels_real", "swap",
+                           "hole", "valid", "tv", "adv")}
+    watch_g = ["enc_1.conv.weight", "enc_3.bn.weight", "dec_2.conv.weight", "last_conv.conv.bias"]
+    watch_d = ["enc_1.conv.weight", "enc_4.bn.bias", "enc_5.conv.weight", "linear.weight"]
+    d_acc_avg = 0.5
+    for s in range(steps):
+        x, gt, mask = orci.synthetic_infill(n, 1, d, h, w, 2000 + s)
+        noise = torch.randn((n, nd, d, h, w), generator=torch.Generator().manual_seed(3000 + s))
+        inputs, masks = torch.cat((x, noise), dim=1), torch.cat((mask, torch.ones_like(noise)), dim=1)
+        st = torch.get_rng_state()
+        lf, lr_, sw = orc.draw_d_labels(n)
+        res["labels_fake"].append(lf.numpy()); res["labels_real"].append(lr_.numpy()); res["swap"].append(sw)
+        torch.set_rng_state(st)
+        if s < warmup:
+            tg, td = True, False
+        elif d_acc_avg > acc_max:
+            tg, td = True, False
+        elif d_acc_avg < acc_min:
+            tg, td = False, True
+        else:
+            tg, td = True, True
+        fake, _ = g(inputs, masks)
+        logits_real, pred_real = dm(gt, masks)
+        logits_fake, pred_fake = dm(fake, masks)
+        d_loss = crit.d_loss(logits_real, logits_fake) * weights["adv"]
+        d_acc_avg = float(0.5 * (ref_metrics.accuracy(pred_real, crit.label_real) + ref_metrics.accuracy(pred_fake, crit.label_fake)))
+        if td:
+            d_opt.zero_grad()
+            d_loss.backward()
+            d_opt.step()
+        fake, _ = g(inputs, masks)
+        logits_fake, _ = dm(fake, masks)
+        terms = rec(x, fake, gt, mask)
+        if s >= warmup:
+            terms["adv"] = crit.g_loss(logits_fake)
+        g_loss = 0.
+        for k in terms:
+            g_loss = g_loss + terms[k] * weights[k]
+        if tg:
+            g_opt.zero_grad()
+            g_loss.backward()
+            g_opt.step()
+        res["d_loss"].append(d_loss.item()); res["g_loss"].append(g_loss.item()); res["d_acc"].append(d_acc_avg)
+        res["train_g"].append(tg); res["train_d"].append(td)
+        for k in ("hole", "valid", "tv", "adv"):
+            res[k].append(terms[k].item() if k in terms else np.nan)
+        gsd, dsd = g.state_dict(), dm.state_dict()
+        for k in watch_g:
+            res.setdefault("G::" + k, []).append(checksums([(k, gsd[k])])[k])
+        for k in watch_d:
+            res.setdefault("D::" + k, []).append(checksums([(k, dsd[k])])[k])
+        res.setdefault("G::enc_2.bn.running_mean", []).append(gsd["enc_2.bn.running_mean"].numpy().copy())
+        res.setdefault("D::enc_2.bn.running_var", []).append(dsd["enc_2.bn.running_var"].numpy().copy())
+        res.setdefault("G::nbt", []).append(int(gsd["enc_2.bn.num_batches_tracked"]))
+        res.setdefault("D::nbt", []).append(int(dsd["enc_2.bn.num_batches_tracked"]))
+        print("infill trajectory step", s, (tg, td), d_acc_avg, d_loss.item(), g_loss.item())
+    out = {k: np.array(v) for k, v in res.items() if len(v)}
+    np.savez_compressed(os.path.join(HERE, "trajectory_infill3d.npz"), meta=json.dumps(
+        dict(d=d, h=h, w=w, n=n, g_layers=g_layers, d_layers=d_layers, steps=steps, warmup=warmup, acc_min=acc_min,
+             acc_max=acc_max, lr=lr, wd=wd, adam_eps=adam_eps, weights=weights, noise_dims=nd, g_seed=61, d_seed=62, torch_seed=444,
+             field_seed0=2000, noise_seed0=3000, loss_type="l2")), **out)
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     if "all" in which or "infill3d" in which:
         golden_infill3d()
+    if "all" in which or "infill3d_trajectory" in which:
+        golden_infill_trajectory()
     if "all" in which or "gan3d" in which:
         golden_gan3d()
     if "all" in which or "keys" in which:

@@ -1,5 +1,5 @@
 """CPU: the partial-convolution U-Net oracle (oracle/infill3d_oracle.py) against vectors produced by the
-reference's own modules (tests/golden/infill3d_c2_16x16x16.npz; make_golden.py infill3d)."""
+reference's own modules (tests/golden/infill3d_c2_32x24x40.npz; make_golden.py infill3d)."""
 import json
 import os
 
@@ -24,7 +24,7 @@ def _cs(t):
 
 @pytest.fixture(scope="module")
 def z(golden_dir):
-    return np.load(os.path.join(golden_dir, "infill3d_c2_16x16x16.npz"))
+    return np.load(os.path.join(golden_dir, "infill3d_c2_32x24x40.npz"))
 
 
 def test_unet3d(z):
@@ -85,3 +85,43 @@ def test_disc3d(z):
     for k in used:
         got = _cs(P[k].grad)
         assert abs(got[2] - ref[k][2]) <= 5e-3 * ref[k][2] + 1e-12, (k, got, ref[k])
+
+
+def test_oracle_loop_matches_reference_trajectory(golden_dir):
+    """Seven iterations of infill3d_gan_module.py:272-375 (warm-up, both, D only, G only -- all four flag states):
+    the oracle's InfillGANStep against the losses, accuracies, flags, weights and running statistics recorded from
+    the reference's modules driven by torch.optim.AdamW (make_golden.py infill3d_trajectory)."""
+    import json
+    import torch
+    z = np.load(os.path.join(golden_dir, "trajectory_infill3d.npz"))
+    m = json.loads(str(z["meta"]))
+    gspec, dspec = oi.unet3d_spec(1 + m["noise_dims"], 1, m["g_layers"]), oi.disc3d_spec(1 + m["noise_dims"], m["d_layers"])
+    st = oi.InfillGANStep(oi.fill_state(gspec, m["g_seed"]), oi.fill_state(dspec, m["d_seed"]), oi.trainable_keys(gspec),
+                          oi.trainable_keys(dspec), m["g_layers"], m["d_layers"], m["weights"], m["loss_type"], m["warmup"],
+                          m["acc_min"], m["acc_max"], lr_g=m["lr"], lr_d=m["lr"], eps=m["adam_eps"], weight_decay=m["wd"], decoupled=True)
+    seen = set()
+    # The first three iterations agree to fp32 rounding (1e-5 bound, measured 1e-7); from the fourth on AdamW's
+    # sign-like early updates (lr 1e-3) have amplified that rounding, measured 1e-5 -> 6e-4 -> 5e-4: bound 3e-3.
+    for s in range(m["steps"]):
+        tol = 1e-5 if s < 3 else 3e-3
+        x, gt, mask = oi.synthetic_infill(m["n"], 1, m["d"], m["h"], m["w"], m["field_seed0"] + s)
+        noise = torch.randn((m["n"], m["noise_dims"], m["d"], m["h"], m["w"]), generator=torch.Generator().manual_seed(m["noise_seed0"] + s))
+        labels = (torch.from_numpy(z["labels_fake"][s]), torch.from_numpy(z["labels_real"][s]), bool(z["swap"][s]))
+        d_loss, g_loss = st.step(x, gt, mask, noise, labels)
+        assert st.last_flags == (bool(z["train_g"][s]), bool(z["train_d"][s]))
+        seen.add(st.last_flags)
+        assert st.d_acc_avg == float(z["d_acc"][s])
+        assert abs(d_loss - z["d_loss"][s]) <= tol * abs(z["d_loss"][s]), (s, d_loss, z["d_loss"][s])
+        assert abs(g_loss - z["g_loss"][s]) <= tol * abs(z["g_loss"][s]), (s, g_loss, z["g_loss"][s])
+        for k in ("hole", "valid", "tv", "adv"):
+            if not np.isnan(z[k][s]):
+                assert abs(st.last_terms[k] - z[k][s]) <= tol * abs(z[k][s]) + 1e-7, (s, k)
+        for tag, P in (("G", st.PG), ("D", st.PD)):
+            for key in [k for k in z.files if k.startswith(tag + "::") and k.endswith(("weight", "bias"))]:
+                # |sum| and sum of squares; the plain sum of a zero-mean tensor cancels and is not compared
+                np.testing.assert_allclose(_cs(P[key[3:]])[1:], z[key][s][1:], rtol=1e-4, err_msg=f"step {s} {key}")
+        _close(st.PG["enc_2.bn.running_mean"].numpy(), z["G::enc_2.bn.running_mean"][s], 10 * tol, "G running_mean")
+        _close(st.PD["enc_2.bn.running_var"].numpy(), z["D::enc_2.bn.running_var"][s], 10 * tol, "D running_var")
+        assert int(st.PG["enc_2.bn.num_batches_tracked"]) == int(z["G::nbt"][s]) == 2 * (s + 1)
+        assert int(st.PD["enc_2.bn.num_batches_tracked"]) == int(z["D::nbt"][s]) == 3 * (s + 1)
+    assert seen == {(True, False), (True, True), (False, True)}
