@@ -3,11 +3,13 @@
 Host-side mirror of the reference's ``architecture/gpsro/infill3d.py`` (PCBActiv3d, PConvUNet3d) and
 ``architecture/common/partialconv3d.py`` (PartialConv3d with multi_channel=True, return_mask=True): same class
 names, constructor arguments and state_dict keys.  Volumes and masks live as folded NHWC tensors [N*D,H,W,C]
-(see deeplab3d.py); masks hold exact 0/1 values in the compute dtype.
+(see deeplab3d.py); masks hold exact 0/1 values.
 
-PartialConv3d = mask window sum (bg_mask_window) + input*mask (bg_mul_rows) + the dense convolution (depth unfold +
-2-D GEMM kernels, deeplab3d.Conv3d) + raw_out*mask_ratio (bg_scale_rows); the updated mask is clamp(window sum, 0, 1)
-broadcast over the output channels.
+PartialConv3d = mask window sum (bg_mask_window) + input*mask written straight into the concatenated layer input
+(ops.MaskedConcatFn) + the dense convolution (depth unfold + 2-D GEMM kernels, deeplab3d.Conv3d) +
+raw_out*mask_ratio (bg_scale_rows).  The updated mask is clamp(window sum, 0, 1) with Cout EQUAL channels, so it is
+kept as one fp32 value per pixel (ops.RowsMask) and only the network's final mask is expanded to the tensor the
+reference returns: no Cout-channel mask tensor is written, resized, concatenated or read inside the network.
 """
 from __future__ import annotations
 
@@ -30,18 +32,34 @@ class PartialConv3d(Conv3d):
         super().__init__(*args, **kwargs)
         self.multi_channel, self.return_mask, self.eps = True, True, eps
 
-    def forward(self, x, mask, n):
-        """x, mask: folded [N*D,H,W,Cin]; returns (output [N*Do,Ho,Wo,Cout], update_mask of the same shape).
+    def forward(self, xs, masks, n):
+        """xs: folded tensors [N*D,H,W,C_i] whose channel concatenation is the layer input; masks: one per segment, a
+        folded per-channel 0/1 tensor or an ops.RowsMask (one value per pixel standing for C_i equal channels, which
+        every update_mask is).  A single tensor / mask is accepted as is.  Returns (output [N*Do,Ho,Wo,Cout],
+        update_mask as RowsMask over Cout channels).
         partialconv3d.py:79-84: ((conv + b - b) * ratio + b) * update_mask = conv * ratio + b * update_mask, since
         ratio already carries the 0/1 update_mask factor."""
+        if not isinstance(xs, (list, tuple)):
+            xs, masks = [xs], [masks]
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
-        upd, ratio, (do, ho, wo) = ops.mask_window(mask, n, k, s, p, self.eps, self.in_channels)
-        raw = super().forward(ops.MulRowsFn.apply(x, mask), n, with_bias=False)
+        dims = (xs[0].shape[0] // n, xs[0].shape[1], xs[0].shape[2])
+        rows = [m for m in masks if isinstance(m, ops.RowsMask)]
+        full = [m for m in masks if not isinstance(m, ops.RowsMask)]
+        assert len(full) <= 1 and sum(m.channels for m in rows) <= self.in_channels
+        upd, ratio, (do, ho, wo) = ops.mask_window(n, dims, k, s, p, self.eps, full[0] if full else None,
+                                                   self.in_channels - sum(m.channels for m in rows), rows)
+        raw = super().forward(ops.MaskedConcatFn.apply(tuple(masks), *xs), n, with_bias=False)
         a = self.arena()
         bs = None if self.bias is None else a.by_param[id(self.bias)]
         out = ops.ScaleRowsFn.apply(raw, ratio, self.bias, upd if bs is not None else None, a, bs)
-        new_mask = ops.rows_from_scalar(upd, n * do, ho, wo, raw.shape[3], raw.dtype)
-        return out, new_mask
+        return out, ops.RowsMask(upd, self.out_channels)
+
+
+def mask_tensor(m, n, dims, channels, dtype):
+    """RowsMask -> folded tensor [N*D,H,W,pad(channels)] with equal channels (what the reference returns as mask)."""
+    if not isinstance(m, ops.RowsMask):
+        return m
+    return ops.rows_from_scalar(m.rows, n * dims[0], dims[1], dims[2], pad_to(channels, vec_of(dtype)), dtype)
 
 
 class PCBActiv3d(BGModule):
@@ -114,10 +132,12 @@ class PConvUNet3d(BGModule):
         h, m = hs[self.layer_size], ms[self.layer_size]
         for i in range(self.layer_size, 0, -1):
             e, em = hs[i - 1], ms[i - 1]
-            size = (e.shape[0] // n, e.shape[1], e.shape[2])
+            src, size = (h.shape[0] // n, h.shape[1], h.shape[2]), (e.shape[0] // n, e.shape[1], e.shape[2])
             h = ops.NearestResize3dFn.apply(h, n, *size)
-            m = ops.NearestResize3dFn.apply(m, n, *size)
-            h, m = ops.concat(h, e), ops.concat(m, em)
-            h, m = getattr(self, 'dec_{:d}'.format(i))(h, m, n)
+            m = ops.nearest_rows(m, n, src, size)
+            # torch.cat of the features and of the masks (infill3d.py:224-225) happens inside the layer
+            h, m = getattr(self, 'dec_{:d}'.format(i))([h, e], [m, em], n)
+        dims = (h.shape[0] // n, h.shape[1], h.shape[2])
         h, m = self.last_conv(h, m, n)
-        return from_folded(h, n, self.output_channels), from_folded(m, n, self.output_channels)
+        return from_folded(h, n, self.output_channels), from_folded(mask_tensor(m, n, dims, self.output_channels, dt), n,
+                                                                    self.output_channels)

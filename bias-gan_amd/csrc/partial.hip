@@ -3,7 +3,9 @@
 // [N*D, H, W, C] as in volume.hip; masks are tensors of the same layout holding exact 0/1 values.
 //   * bg_mask_window: the mask half of PartialConv3d (partialconv3d.py:49-75): window sum of the mask over all
 //     input channels (the "convolution with all-ones weights"), clamp to {0,1}, ratio = winsize/(sum+eps)*clamp.
-//     Integer-valued sums in fp32: exact.
+//     Integer-valued sums in fp32: exact.  Every update_mask has Cout identical channels, so past the first layer
+//     a mask is held as ONE fp32 value per pixel standing for c channels (up to two such segments: the U-Net's
+//     concatenations) -- C times less mask traffic than the reference's Cout-channel mask tensors.
 //   * bg_mul_rows / bg_scale_rows: input*mask before the convolution, raw_out*mask_ratio (+ bias*update_mask)
 //     after it; the same kernels are their own adjoints (mask and ratio are constants).
 //   * bg_resize_nearest3d_fwd/_bwd: F.interpolate(mode='nearest') to an explicit size (infill3d.py:217-222).
@@ -20,7 +22,9 @@ inline unsigned grid1d(long long total) {
 }
 
 struct MaskWinParams {
-    const void* m; int ld, C;
+    const void* m; int ld, C;                       // per-channel mask (may be null)
+    const float* r0; float c0;                      // per-pixel masks standing for c0 / c1 identical channels
+    const float* r1; float c1;
     int N, D, H, W, Do, Ho, Wo, k, stride, pad;
     float winsize, eps;
     float* upd; float* ratio;
@@ -37,8 +41,9 @@ __global__ __launch_bounds__(256) void mask_window_kernel(MaskWinParams P) {
         const int oh = (int)(r % P.Ho); r /= P.Ho;
         const int od = (int)(r % P.Do);
         const int n = (int)(r / P.Do);
-        const T* base = reinterpret_cast<const T*>(P.m) + (long long)n * P.D * P.H * P.W * P.ld;
-        float s = 0.f;
+        const long long vol = (long long)n * P.D * P.H * P.W;
+        const T* base = reinterpret_cast<const T*>(P.m) + vol * P.ld;
+        float s = 0.f, s0 = 0.f, s1 = 0.f;
         for (int kd = 0; kd < P.k; ++kd) {
             const int id = od * P.stride - P.pad + kd;
             if ((unsigned)id >= (unsigned)P.D) continue;
@@ -48,7 +53,11 @@ __global__ __launch_bounds__(256) void mask_window_kernel(MaskWinParams P) {
                 for (int kw = 0; kw < P.k; ++kw) {
                     const int iw = ow * P.stride - P.pad + kw;
                     if ((unsigned)iw >= (unsigned)P.W) continue;
-                    const T* p = base + (((long long)id * P.H + ih) * P.W + iw) * P.ld;
+                    const long long pix = ((long long)id * P.H + ih) * P.W + iw;
+                    if (P.r0) s0 += P.r0[vol + pix];
+                    if (P.r1) s1 += P.r1[vol + pix];
+                    if (!P.m) continue;
+                    const T* p = base + pix * P.ld;
                     for (int c = 0; c < cv; ++c) {
                         Chunk<T> v;
                         v.load(p + c * VEC);
@@ -58,6 +67,7 @@ __global__ __launch_bounds__(256) void mask_window_kernel(MaskWinParams P) {
                 }
             }
         }
+        s += P.c0 * s0 + P.c1 * s1;     // integer-valued and < 2^24: exact in any order
         const float u = fminf(fmaxf(s, 0.f), 1.f);
         P.upd[i] = u;
         P.ratio[i] = P.winsize / (s + P.eps) * u;
@@ -131,6 +141,19 @@ __global__ __launch_bounds__(256) void nearest3d_fwd_kernel(NearestParams P) {
         Chunk<T> v;
         v.load(reinterpret_cast<const T*>(P.x) + ((((long long)n * P.Di + id) * P.Hi + ih) * P.Wi + iw) * P.ldx + c);
         v.store(reinterpret_cast<T*>(P.y) + pix * P.ldy + c);
+    }
+}
+
+__global__ __launch_bounds__(256) void nearest3d_rows_kernel(const float* x, float* y, int N, int Di, int Hi, int Wi, int Do, int Ho,
+                                                             int Wo) {
+    const long long total = (long long)N * Do * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int od = (int)(r % Do);
+        const int n = (int)(r / Do);
+        y[i] = x[(((long long)n * Di + nearest_src(od, Di, Do)) * Hi + nearest_src(oh, Hi, Ho)) * Wi + nearest_src(ow, Wi, Wo)];
     }
 }
 
@@ -226,16 +249,23 @@ extern "C" int bg_blend_f32(const float* m, const float* a, const float* b, floa
     return BG_OK;
 }
 
-extern "C" int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, int32_t N, int32_t D, int32_t H,
-                              int32_t W, int32_t Do, int32_t Ho, int32_t Wo, int32_t k, int32_t stride, int32_t pad, float eps,
-                              float* update_mask, float* ratio, void* stream) {
-    BG_CHECK_ARG(dtype_ok(dtype) && mask && update_mask && ratio && aligned16(mask), "bg_mask_window: bad dtype / pointer");
+extern "C" int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, const float* rows0, int32_t c0,
+                              const float* rows1, int32_t c1, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Do, int32_t Ho,
+                              int32_t Wo, int32_t k, int32_t stride, int32_t pad, float eps, float* update_mask, float* ratio,
+                              void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && (mask || rows0) && update_mask && ratio && (!mask || aligned16(mask)) && (rows0 || !rows1),
+                 "bg_mask_window: bad dtype / pointer");
     const int vec = dtype_vec(dtype);
-    BG_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && k >= 1 && stride >= 1 && pad >= 0 && ld % vec == 0 &&
-                     ld >= (C + vec - 1) / vec * vec, "bg_mask_window: bad sizes");
+    if (!mask) C = 0;
+    if (!rows0) c0 = 0;
+    if (!rows1) c1 = 0;
+    BG_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C >= 0 && c0 >= 0 && c1 >= 0 && C + c0 + c1 > 0 && k >= 1 && stride >= 1 &&
+                     pad >= 0 && (!mask || (C > 0 && ld % vec == 0 && ld >= (C + vec - 1) / vec * vec)) &&
+                     (double)(C + c0 + c1) * k * k * k < 16777216.0, "bg_mask_window: bad sizes");
     BG_CHECK_ARG(Do == (D + 2 * pad - k) / stride + 1 && Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1,
                  "bg_mask_window: output size does not match the conv arithmetic");
-    MaskWinParams P{mask, ld, C, N, D, H, W, Do, Ho, Wo, k, stride, pad, (float)C * k * k * k, eps, update_mask, ratio};
+    MaskWinParams P{mask, ld, C, rows0, (float)c0, rows1, (float)c1, N, D, H, W, Do, Ho, Wo, k, stride, pad,
+                    (float)(C + c0 + c1) * k * k * k, eps, update_mask, ratio};
     const long long total = (long long)N * Do * Ho * Wo;
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((mask_window_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("mask_window_kernel");
@@ -298,6 +328,15 @@ extern "C" int bg_resize_nearest3d_bwd(int32_t dtype, const void* dy, int32_t ld
     const long long total = (long long)N * Di * Hi * Wi * (C / dtype_vec(dtype));
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((nearest3d_bwd_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("nearest3d_bwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_resize_nearest3d_rows(const float* x, float* y, int32_t N, int32_t Di, int32_t Hi, int32_t Wi, int32_t Do,
+                                        int32_t Ho, int32_t Wo, void* stream) {
+    BG_CHECK_ARG(x && y && N > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "bg_resize_nearest3d_rows: bad args");
+    hipLaunchKernelGGL(nearest3d_rows_kernel, dim3(grid1d((long long)N * Do * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, N,
+                       Di, Hi, Wi, Do, Ho, Wo);
+    BG_CHECK_LAUNCH("nearest3d_rows_kernel");
     return BG_OK;
 }
 

@@ -18,7 +18,7 @@ import os as _os
 import torch
 
 from . import _lib as L
-from .runtime import Arena, ParamSlot, StatsPool
+from .runtime import Arena, ParamSlot, StatsPool, vec_of
 
 
 # --------------------------------------------------------------------------- helpers
@@ -696,20 +696,86 @@ def resize_trilinear(x, n, do, ho, wo, out_dtype=None):
 
 
 # ------------------------------------------------------------- partial convolution (row (f)-4)
-def mask_window(mask, n, k, stride, pad, eps, channels=None):
-    """Mask half of PartialConv3d on a folded mask [N*D,H,W,C] (exact 0/1 values): returns
-    (update_mask, mask_ratio) as fp32 [N*Do*Ho*Wo] vectors and the output dims.  No gradient (constants).
-    channels: the layer's in_channels when the folded tensor carries pad lanes (they are not counted)."""
-    mask = nhwc(mask)
-    nd, h, w, c = mask.shape
-    c = c if channels is None else channels
-    d = nd // n
+class RowsMask:
+    """A mask whose `channels` channels are identical: one fp32 value per pixel of the folded volume [N*D*H*W]
+    (every update_mask of PartialConv3d is one, partialconv3d.py:62-64)."""
+    __slots__ = ("rows", "channels")
+
+    def __init__(self, rows, channels):
+        self.rows, self.channels = rows, int(channels)
+
+
+def mask_window(n, dims, k, stride, pad, eps, full=None, full_channels=0, rows=()):
+    """Mask half of PartialConv3d over the channel segments `full` (folded per-channel 0/1 mask [N*D,H,W,C] with
+    `full_channels` real channels, or None) and up to two RowsMask: returns (update_mask, mask_ratio) as fp32
+    [N*Do*Ho*Wo] vectors and the output dims.  No gradient (constants)."""
+    d, h, w = dims
     do, ho, wo = ((x + 2 * pad - k) // stride + 1 for x in (d, h, w))
-    upd = torch.empty(n * do * ho * wo, dtype=torch.float32, device=mask.device)
+    assert len(rows) <= 2 and (full is not None or rows)
+    dev = full.device if full is not None else rows[0].rows.device
+    upd = torch.empty(n * do * ho * wo, dtype=torch.float32, device=dev)
     ratio = torch.empty_like(upd)
-    L.call("bg_mask_window", L.dt(mask.dtype), mask.data_ptr(), ld_of(mask), c, n, d, h, w, do, ho, wo, k, stride, pad, float(eps),
+    r = [(m.rows.data_ptr(), m.channels) for m in rows] + [(None, 0)] * (2 - len(rows))
+    for m in rows:
+        assert m.rows.numel() == n * d * h * w and m.rows.dtype == torch.float32
+    if full is not None:
+        full = nhwc(full)
+        assert tuple(full.shape[:3]) == (n * d, h, w)
+    L.call("bg_mask_window", L.dt(full.dtype) if full is not None else 0, L.ptr(full), 0 if full is None else ld_of(full),
+           full_channels, r[0][0], r[0][1], r[1][0], r[1][1], n, d, h, w, do, ho, wo, k, stride, pad, float(eps),
            upd.data_ptr(), ratio.data_ptr())
     return upd, ratio, (do, ho, wo)
+
+
+def nearest_rows(m: RowsMask, n, src, dst):
+    """F.interpolate(mode='nearest') of a per-pixel mask (infill3d.py:218-222 for the mask)."""
+    y = torch.empty(n * dst[0] * dst[1] * dst[2], dtype=torch.float32, device=m.rows.device)
+    L.call("bg_resize_nearest3d_rows", m.rows.data_ptr(), y.data_ptr(), n, *src, *dst)
+    return RowsMask(y, m.channels)
+
+
+class MaskedConcatFn(torch.autograd.Function):
+    """torch.cat([x_i], dim=1) * torch.cat([mask_i], dim=1) in one pass per segment (infill3d.py:224-225 +
+    partialconv3d.py:77): segment i is written as x_i * mask_i into its channel slice.  mask_i: RowsMask (per pixel) or
+    a folded per-channel tensor.  Masks are constants; the adjoint scales the slices of dy the same way."""
+
+    @staticmethod
+    def forward(ctx, masks, *xs):
+        xs = [nhwc(x) for x in xs]
+        n, h, w, _ = xs[0].shape
+        cs = [x.shape[3] for x in xs]
+        assert all(c % vec_of(xs[0].dtype) == 0 for c in cs[:-1])
+        out = new_act(n, h, w, sum(cs), xs[0].dtype, xs[0].device)
+        ctx.masks, ctx.cs = [m if isinstance(m, RowsMask) else nhwc(m) for m in masks], cs
+        MaskedConcatFn._apply(ctx.masks, cs, xs, [0] * len(xs), out, None)
+        return out
+
+    @staticmethod
+    def _apply(masks, cs, srcs, src_offs, dst, dsts):
+        """forward: srcs[i] (whole) -> dst slice i; backward: slice i of srcs[0] -> dsts[i] (whole)."""
+        rows = srcs[0].shape[0] * srcs[0].shape[1] * srcs[0].shape[2]
+        off = 0
+        for i, (m, c) in enumerate(zip(masks, cs)):
+            if dsts is None:
+                src, so, y, yo = srcs[i], 0, dst, off
+            else:
+                src, so, y, yo = srcs[0], off, dsts[i], 0
+            if y is not None:
+                es = src.element_size()
+                sp, yp = src.data_ptr() + so * es, y.data_ptr() + yo * es
+                if isinstance(m, RowsMask):
+                    L.call("bg_scale_rows", L.dt(src.dtype), sp, ld_of(src), m.rows.data_ptr(), None, None, yp, ld_of(y), rows, c)
+                else:
+                    L.call("bg_mul_rows", L.dt(src.dtype), sp, ld_of(src), m.data_ptr(), ld_of(m), yp, ld_of(y), rows, c)
+            off += c
+
+    @staticmethod
+    def backward(ctx, g):
+        g = nhwc(g)
+        n, h, w, _ = g.shape
+        dxs = [new_act(n, h, w, c, g.dtype, g.device) if ctx.needs_input_grad[1 + i] else None for i, c in enumerate(ctx.cs)]
+        MaskedConcatFn._apply(ctx.masks, ctx.cs, [g], None, None, dxs)
+        return (None, *dxs)
 
 
 def rows_from_scalar(s, n_slices, h, w, c, dtype):
@@ -718,28 +784,6 @@ def rows_from_scalar(s, n_slices, h, w, c, dtype):
     y = new_act(n_slices, h, w, c, dtype, s.device)
     L.call("bg_scale_rows", L.dt(dtype), None, 0, s.data_ptr(), None, None, y.data_ptr(), ld_of(y), n_slices * h * w, c)
     return y
-
-
-class MulRowsFn(torch.autograd.Function):
-    """y = x * m, m a constant tensor of the same folded shape (input * mask_in, partialconv3d.py:77)."""
-
-    @staticmethod
-    def forward(ctx, x, m):
-        x, m = nhwc(x), nhwc(m)
-        n, h, w, c = x.shape
-        y = new_act(n, h, w, c, x.dtype, x.device)
-        L.call("bg_mul_rows", L.dt(x.dtype), x.data_ptr(), ld_of(x), m.data_ptr(), ld_of(m), y.data_ptr(), ld_of(y), n * h * w, c)
-        ctx.save_for_backward(m)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        (m,) = ctx.saved_tensors
-        g = nhwc(g)
-        n, h, w, c = g.shape
-        dx = new_act(n, h, w, c, g.dtype, g.device)
-        L.call("bg_mul_rows", L.dt(g.dtype), g.data_ptr(), ld_of(g), m.data_ptr(), ld_of(m), dx.data_ptr(), ld_of(dx), n * h * w, c)
-        return dx, None
 
 
 class ScaleRowsFn(torch.autograd.Function):

@@ -155,7 +155,11 @@ int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int3
  * bg_mask_window: the mask half of PartialConv3d(multi_channel=True) (partialconv3d.py:49-75): s = sum of the mask
  *   over all C input channels and the k^3 window ("conv with all-ones weights"; the same for every output
  *   channel), update_mask = clamp(s, 0, 1), ratio = C*k^3 / (s + eps) * update_mask; both fp32 [N*Do*Ho*Wo].
- *   C is the layer's real channel count (pad lanes up to the next vector multiple are ignored).
+ *   C is the real channel count of `mask` (pad lanes up to the next vector multiple are ignored).  The window
+ *   sum runs over up to three segments of input channels: `mask` (a per-channel tensor, may be NULL) and rows0 /
+ *   rows1 (fp32 [N*D*H*W], may be NULL): per-pixel masks standing for c0 / c1 identical channels -- what every
+ *   update_mask is (its Cout channels are equal) -- so past the first layer no Cout-channel mask tensor exists.
+ * bg_resize_nearest3d_rows: the nearest resize of such a per-pixel mask.
  * bg_mul_rows:   y = x * m (element-wise; input * mask_in, partialconv3d.py:77).
  * bg_scale_rows: y[r,c] = (x ? x[r,c] : 1) * s[r] + (bias ? bias[c] * t[r] : 0): raw_out * mask_ratio, the bias form
  *   ((raw - b) * ratio + b) * update_mask = conv_nobias * ratio + b * update_mask (ratio already carries the
@@ -166,9 +170,11 @@ int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int3
  * bg_tv_loss_*: total_variation_loss (utils/losses.py:40-44) as it acts on a contiguous fp32 5-D tensor viewed as
  *   [A][D][H][W]: mean |shift along H| + mean |shift along D|; loss accumulated (caller zeroes), dx = coef[0] * d loss/dx.
  * ------------------------------------------------------------------------- */
-int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, int32_t N, int32_t D, int32_t H, int32_t W,
-                   int32_t Do, int32_t Ho, int32_t Wo, int32_t k, int32_t stride, int32_t pad, float eps, float* update_mask,
-                   float* ratio, void* stream);
+int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, const float* rows0, int32_t c0, const float* rows1,
+                   int32_t c1, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Do, int32_t Ho, int32_t Wo, int32_t k,
+                   int32_t stride, int32_t pad, float eps, float* update_mask, float* ratio, void* stream);
+int bg_resize_nearest3d_rows(const float* x, float* y, int32_t N, int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho,
+                             int32_t Wo, void* stream);
 int bg_mul_rows(int32_t dtype, const void* x, int32_t ldx, const void* m, int32_t ldm, void* y, int32_t ldy, int64_t rows,
                 int32_t C, void* stream);
 int bg_scale_rows(int32_t dtype, const void* x, int32_t ldx, const float* s, const float* bias, const float* t, void* y,

@@ -67,7 +67,9 @@ def test_partial_conv3d(dtype, cin, cout, k, s, p, bias):
     cp = pad_to(cin, vec_of(dtype))
     xd = x.to(DEV).requires_grad_(True)
     y, ym = m(d3.to_folded(xd, cp, dtype), d3.to_folded(mask.to(DEV), cp, dtype), n)
-    yo, ymo = d3.from_folded(y, n, cout), d3.from_folded(ym, n, cout)
+    assert isinstance(ym, ops.RowsMask) and ym.channels == cout
+    yo = d3.from_folded(y, n, cout)
+    ymo = d3.from_folded(i3.mask_tensor(ym, n, tuple(ref.shape[2:]), cout, dtype), n, cout)
     assert torch.equal(ymo.cpu(), ref_mask)
     close(yo.detach().cpu(), ref.detach(), tol(dtype) * (1 if dtype == F32 else 3), "y")
     yo.backward(go.to(DEV))
@@ -76,6 +78,54 @@ def test_partial_conv3d(dtype, cin, cout, k, s, p, bias):
     close(m.weight.grad.cpu(), wr.grad, 1e-3 if dtype == F32 else 3e-2, "dw")
     if bias:
         close(m.bias.grad.cpu(), br.grad, 1e-3 if dtype == F32 else 3e-2, "dbias")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_partial_conv3d_on_concatenated_segments(dtype):
+    """A decoder layer's input: [upsampled features with a per-pixel mask | skip features with a per-pixel mask |
+    the network input with its per-channel mask] against the oracle on the concatenated tensors."""
+    n, d, h, w, cs, cout = 2, 5, 6, 7, (16, 8, 3), 24
+    cin = sum(cs)
+    m = i3.PartialConv3d(cin, cout, 3, 1, 1, bias=False, eps=1e-6).set_compute_dtype(dtype)
+    wt = rnd((cout, cin, 3, 3, 3), 11, dtype, 1.0 / np.sqrt(cin * 27))
+    m.weight.data.copy_(wt)
+    m.to(DEV)
+    g = torch.Generator().manual_seed(12)
+    xs = [rnd((n, c, d, h, w), 13 + i, dtype) for i, c in enumerate(cs)]
+    pix = [(torch.rand((n, 1, d, h, w), generator=g) > 0.5).float() for _ in range(2)]
+    pix[0][1, :, 1:4, 1:5, 2:6] = 0.0
+    pix[1][1, :, 1:4, 1:5, 2:6] = 0.0
+    full = (torch.rand((n, cs[2], d, h, w), generator=g) > 0.5).float()
+    full[1, :, 1:4, 1:5, 2:6] = 0.0                       # a region no segment covers: update_mask == 0
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr = wt.clone().requires_grad_(True)
+    ref, ref_mask = oi.partial_conv3d(torch.cat(xr, 1), torch.cat([pix[0].expand(-1, cs[0], -1, -1, -1),
+                                                                  pix[1].expand(-1, cs[1], -1, -1, -1), full], 1), wr, None, 1, 1)
+    assert float(ref_mask.min()) == 0.0
+    go = rnd(tuple(ref.shape), 17, dtype)
+    ref.backward(go)
+    vec = vec_of(dtype)
+    xd = [x.to(DEV).requires_grad_(True) for x in xs]
+    masks = [ops.RowsMask(pix[0].reshape(-1).to(DEV), cs[0]), ops.RowsMask(pix[1].reshape(-1).to(DEV), cs[1]),
+             d3.to_folded(full.to(DEV), pad_to(cs[2], vec), dtype)]
+    y, ym = m([d3.to_folded(x, pad_to(c, vec), dtype) for x, c in zip(xd, cs)], masks, n)
+    assert torch.equal(ym.rows.cpu().reshape(n, 1, d, h, w).expand(-1, cout, -1, -1, -1), ref_mask)
+    yo = d3.from_folded(y, n, cout)
+    close(yo.detach().cpu(), ref.detach(), tol(dtype) * (1 if dtype == F32 else 3), "y")
+    yo.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    for i in range(3):
+        close(xd[i].grad.cpu(), xr[i].grad, 3 * tol(dtype), f"dx{i}")
+    close(m.weight.grad.cpu(), wr.grad, 1e-3 if dtype == F32 else 3e-2, "dw")
+
+
+@pytest.mark.parametrize("src,dst", [((2, 3, 4), (4, 6, 8)), ((2, 2, 3), (3, 3, 5)), ((1, 1, 1), (2, 2, 3))])
+def test_nearest_resize_of_pixel_masks(src, dst):
+    n = 2
+    mk = (torch.rand((n, 1) + src, generator=torch.Generator().manual_seed(19)) > 0.5).float()
+    got = ops.nearest_rows(ops.RowsMask(mk.reshape(-1).to(DEV), 5), n, src, dst)
+    assert got.channels == 5
+    assert torch.equal(got.rows.cpu().reshape((n, 1) + dst), F.interpolate(mk, size=dst, mode="nearest"))
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
