@@ -47,7 +47,7 @@ struct GemmConvParams {
     int tiles_c, tiles_p;
     double* stat_sum;  // optional per-output-channel sum / sum of squares of the STORED outputs
     double* stat_sq;   // (BatchNorm statistics fused into the epilogue); NULL = off
-    int stat_tiles_per_group;  // pixel tiles per statistic group (sum/sumsq are [groups][NO]); 0 = one group
+    int stat_group_pix;  // pixels per statistic group (sum/sumsq are [groups][NO]; a multiple of the pixel tile); 0 = one group
     int CKp;       // K stride of one tap inside the (zero-padded) weight copy
     int in_bytes;  // exact extent of the activation operand (buffer-load range check)
     int w_bytes;
@@ -119,7 +119,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // P.stat_sum set it also reduces sum(y) and sum(y^2) of the values AS STORED
 // (after rounding to T) over the tile's 128 pixels: 16-lane shuffle tree, the two
 // pixel-waves are combined through LDS, one fp64 atomic per channel per tile.
-template <typename T, int TCH = TILE>
+template <typename T, int TCH = TILE, int TP = TILE>
 __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&acc)[4][4], long long p_base, int c_base,
                                               int wave_c, int wave_p, int lane, char* smem) {
     T* out = reinterpret_cast<T*>(P.out);
@@ -177,6 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&a
                 s2[i][e] = row16_sum(s2[i][e]);
             }
         __syncthreads();  // every wave is done reading the staging ring: reuse it
+        constexpr int PW = TP / 64;                   // pixel-waves of the tile
         float* red = reinterpret_cast<float*>(smem);  // [wave_p][TCH channels][2]
         if (r16 == 0) {
 #pragma unroll
@@ -193,10 +194,16 @@ __device__ __forceinline__ void conv_epilogue(const GemmConvParams& P, f32x4 (&a
         if (t < TCH && c_base + t < P.NO) {
             // statistic groups are contiguous pixel ranges (sub-batches normalised separately); a tile
             // never straddles two (checked on the host)
-            const int grp = P.stat_tiles_per_group ? (int)(p_base / TILE) / P.stat_tiles_per_group : 0;
+            const int grp = P.stat_group_pix ? (int)(p_base / P.stat_group_pix) : 0;
             const long long o = (long long)grp * P.NO + c_base + t;
-            atomicAdd(P.stat_sum + o, (double)(red[t * 2] + red[(TCH + t) * 2]));
-            atomicAdd(P.stat_sq + o, (double)(red[t * 2 + 1] + red[(TCH + t) * 2 + 1]));
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wp = 0; wp < PW; ++wp) {
+                a1 += red[(wp * TCH + t) * 2];
+                a2 += red[(wp * TCH + t) * 2 + 1];
+            }
+            atomicAdd(P.stat_sum + o, (double)a1);
+            atomicAdd(P.stat_sq + o, (double)a2);
         }
     }
 }
@@ -382,19 +389,20 @@ __device__ __forceinline__ void wait_vmcnt() {
 // The kernel is bound by operand delivery into LDS, not by the MFMAs (an ablation build without the
 // MFMAs runs as fast, one without the loads 1.5-1.8x faster); 256 x 128 moves 25 % fewer operand bytes
 // per FLOP than 128 x 128 and puts 16 waves on a CU (2 workgroups x 72 KiB of LDS).
-template <typename T, int BKB, int NBUF, int TCH>
-__global__ __launch_bounds__(TCH * 2) void gemm_conv_dma_kernel(GemmConvParams P) {
+template <typename T, int BKB, int NBUF, int TCH, int TP = TILE>
+__global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvParams P) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BK = BKB / ES;
     constexpr int CPR = BKB / 16;   // chunks per row
     constexpr int RPG = 64 / CPR;   // tile rows covered by one wave-wide DMA (1 KiB)
-    constexpr int NW = TCH / 32;    // waves per workgroup
-    constexpr int ROWS_A = TCH / NW, ROWS_B = TILE / NW;  // tile rows a wave stages per operand: 32 and 32 | 16
+    constexpr int PW = TP / 64;                 // pixel-waves; every wave owns a 64 x 64 sub-tile
+    constexpr int NW = (TCH / 64) * PW;         // waves per workgroup
+    constexpr int ROWS_A = TCH / NW, ROWS_B = TP / NW;  // tile rows a wave stages per operand
     constexpr int NGA = ROWS_A / RPG, NGB = ROWS_B / RPG;  // DMAs per wave per K-step
     constexpr int NG = NGA > NGB ? NGA : NGB;
     constexpr int GROUP = NGA + NGB;  // VMEM ops per wave per K-step
     constexpr int TILE_BYTES = TCH * BKB;               // A (weight) rows of one stage
-    constexpr int STAGE_BYTES = (TCH + TILE) * BKB;
+    constexpr int STAGE_BYTES = (TCH + TP) * BKB;
     constexpr int DIST = NBUF - 1;  // K-steps in flight ahead of the MFMAs
     static_assert(NGA >= 1 && NGB >= 1, "a wave stages at least one DMA per operand");
     static_assert(DIST == 2 || DIST == 3, "counted waits are written for 2 or 3 K-steps of prefetch");
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(TCH * 2) void gemm_conv_dma_kernel(GemmConvParams P
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_c = wave >> 1, wave_p = wave & 1;
+    const int wave_c = wave / PW, wave_p = wave % PW;
 
     const int nblk = gridDim.x;
     int bid = blockIdx.x;
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(TCH * 2) void gemm_conv_dma_kernel(GemmConvParams P
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
     }
     const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
-    const long long p_base = (long long)tile_p * TILE;
+    const long long p_base = (long long)tile_p * TP;
     const int c_base = tile_c * TCH;
     const int RS = P.KH * P.KW;
 
@@ -455,7 +463,11 @@ __global__ __launch_bounds__(TCH * 2) void gemm_conv_dma_kernel(GemmConvParams P
     }
 
     const int ksteps_per_tap = (P.CK + BK - 1) / BK;
+#ifdef ABL_KT1   // ablation: one K-step only -> what a tile costs besides its K loop
+    const int KT = 1;
+#else
     const int KT = RS * ksteps_per_tap;
+#endif
 #pragma unroll
     for (int g = 0; g < NGB; ++g) tail_cut[g] = (ksteps_per_tap - 1) * BK + chk16[g] / ES >= P.CK;
 
@@ -543,7 +555,16 @@ __global__ __launch_bounds__(TCH * 2) void gemm_conv_dma_kernel(GemmConvParams P
         nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
     }
 
-    conv_epilogue<T, TCH>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
+#ifdef ABL_NO_EPI   // ablation: no stores / statistics (one never-taken store keeps the K loop alive)
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) chk += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (chk == 1.2345e-33f) reinterpret_cast<float*>(P.out)[0] = chk;
+#else
+    conv_epilogue<T, TCH, TP>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
+#endif
 }
 
 // ------------------------------------------------------------------ wgrad ----
@@ -845,8 +866,25 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     // 256 out-channel rows per tile wherever that does not add padding (NO <= 128 stays on 128 x 128)
     const bool tall = dma_mode == 1 && tch_max >= 256 && P.NO > TILE;
     const int tch = tall ? 256 : TILE;
+    // 256 x 256 tile (one 1024-thread workgroup per CU instead of two 256 x 128 ones): a third fewer operand bytes
+    // through the LDS-DMA path per FLOP, measured 1.1-1.2x faster per FLOP in the K loop -- but coarser rounds of the
+    // chip and no second workgroup to hide prologue / epilogue behind.  Chosen per launch by a round count model
+    // (units: one 256 x 128 tile alone on a CU): 512 co-resident 256 x 128 tiles cost 2 per full round, a remainder
+    // of <= 256 tiles 1; a round of 256 x 256 tiles costs 2 / 1.13.  Short reductions (< 16 K-steps) stay narrow.
+    // BGAMD_TP: 0 = never, 256 = wherever legal, unset = by the model.
+    static const int tp_mode = getenv("BGAMD_TP") ? atoi(getenv("BGAMD_TP")) : -1;
+    bool wide = tall && tp_mode != 0 && (P.stat_group_pix == 0 || P.stat_group_pix % 256 == 0);
+    if (wide && tp_mode < 0) {
+        const long long tc = (P.NO + 255) / 256, t128 = tc * ((P.M + 127) / 128), t256 = tc * ((P.M + 255) / 256);
+        const long long rem = t128 % 512;
+        const double cost128 = 2.0 * (double)(t128 / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 : 2.0);
+        const double cost256 = (double)((t256 + 255) / 256) * (2.0 / 1.13);
+        const long long ksteps = (long long)P.KH * P.KW * ((P.CK + 31) / 32);
+        wide = ksteps >= 16 && cost256 < 0.98 * cost128;
+    }
+    const int tp = wide ? 256 : TILE;
     P.tiles_c = (P.NO + tch - 1) / tch;
-    P.tiles_p = (int)((P.M + TILE - 1) / TILE);
+    P.tiles_p = (int)((P.M + tp - 1) / tp);
     const long long nblk = (long long)P.tiles_c * P.tiles_p;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         bg_set_error("conv: grid too large");
@@ -859,7 +897,20 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     bool use128 = pad128 <= pad64 + pad64 / 32;
     if (const char* e = getenv("BGAMD_BKB")) use128 = atoi(e) == 128;  // tuning knob
     if (dma_mode) {
-        if (tall) {
+        if (wide) {
+            static const int nbuf = getenv("BGAMD_TP_NBUF") ? atoi(getenv("BGAMD_TP_NBUF")) : 3;
+            const size_t sh = (size_t)nbuf * (256 + 256) * 64;  // 96 / 128 KiB
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 64, 3, 256, 256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 512 * 64);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 64, 4, 256, 256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64);
+                once = true;
+            }
+            if (nbuf == 3) hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3, 256, 256>), dim3((unsigned)nblk), dim3(1024), sh, st, P);
+            else hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 4, 256, 256>), dim3((unsigned)nblk), dim3(1024), sh, st, P);
+        } else if (tall) {
             const size_t sh = 3 * (256 + TILE) * 64;  // 72 KiB
             static bool once = false;
             if (!once) {
@@ -929,7 +980,7 @@ extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const v
     P.transposed = 0;
     P.M = (long long)d->N * d->Ho * d->Wo;
     P.stat_sum = sum; P.stat_sq = sumsq;
-    P.stat_tiles_per_group = groups > 1 ? (int)(M_ / groups / TILE) : 0;
+    P.stat_group_pix = groups > 1 ? (int)(M_ / groups) : 0;
     if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
     return launch_gemm_conv<float>(P, (hipStream_t)stream);
 }

@@ -476,6 +476,40 @@ def test_conv_fwd_fused_statistics(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_wide_tile_launch(dtype):
+    """A launch the round-count model sends to the 256 x 256 tile (2 x 1024 tiles of 256 x 128 against 4 rounds of
+    256 x 256, 16 K-steps): outputs, per-group statistics from the 4-pixel-wave epilogue, rows beyond M and the
+    partial last channel tile."""
+    n, h, w, cin, cout = 2, 256, 255, 512, 264          # M = 130 560: the last pixel tile is partial
+    x = rnd((n, cin, h, w), 31, dtype)
+    wt = rnd((cout, cin, 1, 1), 32, dtype, 1.0 / math.sqrt(cin))
+    desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, 1, 1, 0, 1, up(cin, dtype), up(cout, dtype))
+    xb, xv = to_nhwc(x, dtype)
+    wpk, _ = pack(krsc(wt, dtype), dtype)
+    yb = torch.zeros(n, ho, wo, up(cout, dtype), dtype=dtype, device=DEV)
+    st = torch.zeros(2, 1, up(cout, dtype), dtype=torch.float64, device=DEV)
+    L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yb.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), 1)
+    ref = F.conv2d(x, wt)
+    assert_close(from_nhwc(yb, cout), ref, tol(dtype), "fwd")
+    y = yb.double()
+    assert_close(st[0, 0].cpu(), y.sum((0, 1, 2)).cpu(), 1e-5, "sum")
+    assert_close(st[1, 0].cpu(), (y * y).sum((0, 1, 2)).cpu(), 1e-5, "sumsq")
+    # two statistic groups of 65 536 pixels (whole 256-pixel tiles)
+    x2, desc2 = x[:, :, :, :128].contiguous(), conv_desc(dtype, n, h, 128, cin, cout, 1, 1, 0, 1, up(cin, dtype), up(cout, dtype))[0]
+    xb2, xv2 = to_nhwc(torch.cat([x2, x2 + 1.0], 0), dtype)
+    desc2 = conv_desc(dtype, 2 * n, h, 128, cin, cout, 1, 1, 0, 1, up(cin, dtype), up(cout, dtype))[0]
+    yb2 = torch.zeros(2 * n, h, 128, up(cout, dtype), dtype=dtype, device=DEV)
+    st2 = torch.zeros(2, 2, up(cout, dtype), dtype=torch.float64, device=DEV)
+    L.call("bg_conv2d_fwd_stats", desc2, xv2.data_ptr(), wpk.data_ptr(), yb2.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(), 2)
+    y2 = yb2.double()
+    for g in range(2):
+        yg = y2[n * g:n * g + n]
+        assert_close(st2[0, g].cpu(), yg.sum((0, 1, 2)).cpu(), 1e-5, f"sum[{g}]")
+        assert_close(st2[1, g].cpu(), (yg * yg).sum((0, 1, 2)).cpu(), 1e-5, f"sumsq[{g}]")
+    assert_close(from_nhwc(yb2[:n], cout), F.conv2d(x2, wt), tol(dtype), "fwd, group 0")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fwd_fused_statistics_per_group(dtype):
     """groups = 2: sums of the two halves of the batch land in separate rows."""
     n, h, w, cin, cout, k = 4, 16, 16, 24, 264, 1       # 2 images per group = 512 pixels = 4 tiles
