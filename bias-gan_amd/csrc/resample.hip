@@ -226,6 +226,53 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_vec_kernel(const T* src, int
     }
 }
 
+// Four pixels per thread (HW % 4 == 0, 16-byte aligned planes): float4 loads / stores on the NCHW side -- a
+// quarter of the instructions of the one-pixel form for the same bytes.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_vec4_kernel(const float* src, T* dst, int C, int HW, int Cp, int ldd) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const int n = blockIdx.y;
+    const float* s = src + (long long)n * C * HW + p;
+    T* d = dst + ((long long)n * HW + p) * ldd;
+    for (int c0 = 0; c0 < Cp; c0 += VEC) {
+        f32x4 v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            v[e] = (c0 + e < C) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s + (long long)(c0 + e) * HW))
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.set(e, v[e][q]);
+            o.store(d + (long long)q * ldd + c0);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_vec4_kernel(const T* src, int lds, float* dst, int C, int HW) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const int n = blockIdx.y;
+    const T* s = src + ((long long)n * HW + p) * lds;
+    float* d = dst + (long long)n * C * HW + p;
+    for (int c0 = 0; c0 < C; c0 += VEC) {
+        Chunk<T> v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q].load(s + (long long)q * lds + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (c0 + e < C) {
+                f32x4 o = {v[0].get(e), v[1].get(e), v[2].get(e), v[3].get(e)};
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(d + (long long)(c0 + e) * HW));
+            }
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* src, int lds, float* dst, int N, int C, int HW) {
     const long long total = (long long)N * HW;
@@ -374,6 +421,12 @@ extern "C" int bg_nchw_to_nhwc(int32_t dst_dtype, const float* src, void* dst, i
                  "bg_nchw_to_nhwc: bad args");
     const long long total = (long long)N * HW;
     const int vec = dtype_vec(dst_dtype);
+    if (aligned16(dst) && aligned16(src) && Cp % vec == 0 && ldd % vec == 0 && N <= 65535 && HW % 4 == 0) {
+        BG_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_vec4_kernel<T>), dim3((HW / 4 + 255) / 256, N), dim3(256),
+                                                           0, (hipStream_t)stream, src, (T*)dst, C, HW, Cp, ldd));
+        BG_CHECK_LAUNCH("nchw_to_nhwc_vec4_kernel");
+        return BG_OK;
+    }
     if (aligned16(dst) && Cp % vec == 0 && ldd % vec == 0 && N <= 65535) {
         BG_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_vec_kernel<T>), dim3((HW + 255) / 256, N), dim3(256),
                                                            0, (hipStream_t)stream, src, (T*)dst, C, HW, Cp, ldd));
@@ -392,6 +445,12 @@ extern "C" int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, 
     const long long total = (long long)N * HW;
     const int vec = dtype_vec(src_dtype);
     // the vector form reads whole 16-byte chunks: the row must hold them (lds >= C rounded up)
+    if (aligned16(src) && aligned16(dst) && lds % vec == 0 && lds >= (C + vec - 1) / vec * vec && N <= 65535 && HW % 4 == 0) {
+        BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_vec4_kernel<T>), dim3((HW / 4 + 255) / 256, N), dim3(256),
+                                                           0, (hipStream_t)stream, (const T*)src, lds, dst, C, HW));
+        BG_CHECK_LAUNCH("nhwc_to_nchw_vec4_kernel");
+        return BG_OK;
+    }
     if (aligned16(src) && lds % vec == 0 && lds >= (C + vec - 1) / vec * vec && N <= 65535) {
         BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_vec_kernel<T>), dim3((HW + 255) / 256, N), dim3(256),
                                                            0, (hipStream_t)stream, (const T*)src, lds, dst, C, HW));

@@ -444,6 +444,22 @@ def test_adam_matches_torch():
         assert torch.equal(plp.cpu(), p.cpu().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,cp,ld", [(16, 16, 32), (5, 8, 8), (20, 24, 40)])
+def test_layout_four_pixel_form(dtype, c, cp, ld):
+    """HW % 4 == 0: the float4 forms of bg_nchw_to_nhwc / bg_nhwc_to_nchw (pad lanes zeroed, the row tail beyond Cp
+    untouched, exact round trip)."""
+    n, h, w = 3, 12, 43 * 4
+    xs = rnd((n, c, h, w), 41, torch.float32).to(DEV)
+    nh = torch.full((n, h, w, ld), 3.0, dtype=dtype, device=DEV)
+    L.call("bg_nchw_to_nhwc", L.dt(dtype), xs.data_ptr(), nh.data_ptr(), n, c, h * w, cp, ld)
+    assert torch.equal(nh[..., :c].permute(0, 3, 1, 2).float(), xs.to(dtype).float())
+    assert (nh[..., c:cp] == 0).all() and (nh[..., cp:] == 3.0).all()
+    back = torch.zeros(n, c, h, w, device=DEV)
+    L.call("bg_nhwc_to_nchw", L.dt(dtype), nh.data_ptr(), ld, back.data_ptr(), n, c, h * w)
+    assert torch.equal(back, nh[..., :c].permute(0, 3, 1, 2).float())
+
+
 def test_bad_arguments_raise():
     d = L.ConvDesc(L.BF16, 1, 8, 8, 12, 8, 8, 16, 1, 1, 1, 0, 1, 12, 16)  # Cin not a multiple of 8
     z = torch.zeros(8, device=DEV)
