@@ -81,7 +81,7 @@ _SIGS = {
     "bg_depth_resize_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_depth_resize_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_mask_window": [c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                       c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],
+                       c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],
     "bg_resize_nearest3d_rows": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_mul_rows": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp],
     "bg_scale_rows": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp],

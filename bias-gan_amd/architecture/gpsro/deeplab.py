@@ -75,15 +75,17 @@ class Conv2d(BGModule):
             nn.init.uniform_(self.bias, -bound, bound)
         self._bg_param_layout = {"weight": _dw_layout if groups > 1 else _conv_layout, "bias": _vec_layout}
 
-    def forward(self, x, stats=None):
-        """x: NHWC activation (padded channels).  stats: see ops.Conv2dFn."""
+    def forward(self, x, stats=None, with_bias=True):
+        """x: NHWC activation (padded channels).  stats: see ops.Conv2dFn.  with_bias=False leaves the bias to the
+        caller (the partial convolution adds it after its mask ratio)."""
         a = self.arena()
         ws = a.by_param[id(self.weight)]
         if self.groups > 1:
             return ops.DwConv3x3Fn.apply(x, self.weight, a, ws, self.stride[0], self.dilation[0])
-        bs = None if self.bias is None else a.by_param[id(self.bias)]
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, bs, self.stride[0], self.padding[0], self.dilation[0],
-                                  stats)
+        if self.bias is None or not with_bias:
+            return ops.Conv2dFn.apply(x, self.weight, None, a, ws, None, self.stride[0], self.padding[0], self.dilation[0], stats)
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, a.by_param[id(self.bias)], self.stride[0], self.padding[0],
+                                  self.dilation[0], stats)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size[0]}, s={self.stride[0]}, groups={self.groups}"

@@ -23,6 +23,30 @@ from .deeplab3d import Conv3d, apply_norm3d, from_folded, to_folded
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 
 
+def partial_forward(conv, run_conv, xs, masks, n, planar):
+    """The partial convolution around a dense convolution `run_conv(x)` (bias left out) of the container `conv`:
+    mask window sum -> input * mask written into the concatenated layer input -> convolution -> * mask_ratio
+    (+ bias * update_mask).  xs: folded tensors [N*D,H,W,C_i] whose channel concatenation is the layer input; masks:
+    one per segment, a folded per-channel 0/1 tensor or an ops.RowsMask (one value per pixel standing for C_i equal
+    channels, which every update_mask is).  Returns (output, update_mask as RowsMask over Cout channels).
+    partialconv3d.py:79-84 / partialconv2d.py:79-84: ((conv + b - b) * ratio + b) * update_mask
+    = conv * ratio + b * update_mask, since ratio already carries the 0/1 update_mask factor."""
+    if not isinstance(xs, (list, tuple)):
+        xs, masks = [xs], [masks]
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    dims = (xs[0].shape[0] // n, xs[0].shape[1], xs[0].shape[2])
+    rows = [m for m in masks if isinstance(m, ops.RowsMask)]
+    full = [m for m in masks if not isinstance(m, ops.RowsMask)]
+    assert len(full) <= 1 and sum(m.channels for m in rows) <= conv.in_channels
+    upd, ratio, _ = ops.mask_window(n, dims, k, s, p, conv.eps, full[0] if full else None,
+                                    conv.in_channels - sum(m.channels for m in rows), rows, planar=planar)
+    raw = run_conv(ops.MaskedConcatFn.apply(tuple(masks), *xs))
+    a = conv.arena()
+    bs = None if conv.bias is None else a.by_param[id(conv.bias)]
+    out = ops.ScaleRowsFn.apply(raw, ratio, conv.bias, upd if bs is not None else None, a, bs)
+    return out, ops.RowsMask(upd, conv.out_channels)
+
+
 class PartialConv3d(Conv3d):
     """nn.Conv3d subclass of the reference (partialconv3d.py:14-92) for multi_channel=True, return_mask=True."""
 
@@ -33,26 +57,8 @@ class PartialConv3d(Conv3d):
         self.multi_channel, self.return_mask, self.eps = True, True, eps
 
     def forward(self, xs, masks, n):
-        """xs: folded tensors [N*D,H,W,C_i] whose channel concatenation is the layer input; masks: one per segment, a
-        folded per-channel 0/1 tensor or an ops.RowsMask (one value per pixel standing for C_i equal channels, which
-        every update_mask is).  A single tensor / mask is accepted as is.  Returns (output [N*Do,Ho,Wo,Cout],
-        update_mask as RowsMask over Cout channels).
-        partialconv3d.py:79-84: ((conv + b - b) * ratio + b) * update_mask = conv * ratio + b * update_mask, since
-        ratio already carries the 0/1 update_mask factor."""
-        if not isinstance(xs, (list, tuple)):
-            xs, masks = [xs], [masks]
-        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
-        dims = (xs[0].shape[0] // n, xs[0].shape[1], xs[0].shape[2])
-        rows = [m for m in masks if isinstance(m, ops.RowsMask)]
-        full = [m for m in masks if not isinstance(m, ops.RowsMask)]
-        assert len(full) <= 1 and sum(m.channels for m in rows) <= self.in_channels
-        upd, ratio, (do, ho, wo) = ops.mask_window(n, dims, k, s, p, self.eps, full[0] if full else None,
-                                                   self.in_channels - sum(m.channels for m in rows), rows)
-        raw = super().forward(ops.MaskedConcatFn.apply(tuple(masks), *xs), n, with_bias=False)
-        a = self.arena()
-        bs = None if self.bias is None else a.by_param[id(self.bias)]
-        out = ops.ScaleRowsFn.apply(raw, ratio, self.bias, upd if bs is not None else None, a, bs)
-        return out, ops.RowsMask(upd, self.out_channels)
+        """See partial_forward; volumes folded as [N*D,H,W,C]."""
+        return partial_forward(self, lambda x: Conv3d.forward(self, x, n, with_bias=False), xs, masks, n, planar=False)
 
 
 def mask_tensor(m, n, dims, channels, dtype):

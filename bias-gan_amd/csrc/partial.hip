@@ -26,6 +26,7 @@ struct MaskWinParams {
     const float* r0; float c0;                      // per-pixel masks standing for c0 / c1 identical channels
     const float* r1; float c1;
     int N, D, H, W, Do, Ho, Wo, k, stride, pad;
+    int kd, sd, pd;                                 // depth window (1, 1, 0 for the 2-D PartialConv2d)
     float winsize, eps;
     float* upd; float* ratio;
 };
@@ -44,8 +45,8 @@ __global__ __launch_bounds__(256) void mask_window_kernel(MaskWinParams P) {
         const long long vol = (long long)n * P.D * P.H * P.W;
         const T* base = reinterpret_cast<const T*>(P.m) + vol * P.ld;
         float s = 0.f, s0 = 0.f, s1 = 0.f;
-        for (int kd = 0; kd < P.k; ++kd) {
-            const int id = od * P.stride - P.pad + kd;
+        for (int kd = 0; kd < P.kd; ++kd) {
+            const int id = od * P.sd - P.pd + kd;
             if ((unsigned)id >= (unsigned)P.D) continue;
             for (int kh = 0; kh < P.k; ++kh) {
                 const int ih = oh * P.stride - P.pad + kh;
@@ -251,8 +252,8 @@ extern "C" int bg_blend_f32(const float* m, const float* a, const float* b, floa
 
 extern "C" int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, const float* rows0, int32_t c0,
                               const float* rows1, int32_t c1, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Do, int32_t Ho,
-                              int32_t Wo, int32_t k, int32_t stride, int32_t pad, float eps, float* update_mask, float* ratio,
-                              void* stream) {
+                              int32_t Wo, int32_t k, int32_t stride, int32_t pad, int32_t planar, float eps, float* update_mask,
+                              float* ratio, void* stream) {
     BG_CHECK_ARG(dtype_ok(dtype) && (mask || rows0) && update_mask && ratio && (!mask || aligned16(mask)) && (rows0 || !rows1),
                  "bg_mask_window: bad dtype / pointer");
     const int vec = dtype_vec(dtype);
@@ -262,10 +263,11 @@ extern "C" int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32
     BG_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C >= 0 && c0 >= 0 && c1 >= 0 && C + c0 + c1 > 0 && k >= 1 && stride >= 1 &&
                      pad >= 0 && (!mask || (C > 0 && ld % vec == 0 && ld >= (C + vec - 1) / vec * vec)) &&
                      (double)(C + c0 + c1) * k * k * k < 16777216.0, "bg_mask_window: bad sizes");
-    BG_CHECK_ARG(Do == (D + 2 * pad - k) / stride + 1 && Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1,
+    const int kd = planar ? 1 : k, sd = planar ? 1 : stride, pd = planar ? 0 : pad;
+    BG_CHECK_ARG(Do == (D + 2 * pd - kd) / sd + 1 && Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1,
                  "bg_mask_window: output size does not match the conv arithmetic");
-    MaskWinParams P{mask, ld, C, rows0, (float)c0, rows1, (float)c1, N, D, H, W, Do, Ho, Wo, k, stride, pad,
-                    (float)(C + c0 + c1) * k * k * k, eps, update_mask, ratio};
+    MaskWinParams P{mask, ld, C, rows0, (float)c0, rows1, (float)c1, N, D, H, W, Do, Ho, Wo, k, stride, pad, kd, sd, pd,
+                    (float)(C + c0 + c1) * kd * k * k, eps, update_mask, ratio};
     const long long total = (long long)N * Do * Ho * Wo;
     BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((mask_window_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("mask_window_kernel");

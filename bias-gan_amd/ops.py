@@ -705,12 +705,15 @@ class RowsMask:
         self.rows, self.channels = rows, int(channels)
 
 
-def mask_window(n, dims, k, stride, pad, eps, full=None, full_channels=0, rows=()):
+def mask_window(n, dims, k, stride, pad, eps, full=None, full_channels=0, rows=(), planar=False):
     """Mask half of PartialConv3d over the channel segments `full` (folded per-channel 0/1 mask [N*D,H,W,C] with
     `full_channels` real channels, or None) and up to two RowsMask: returns (update_mask, mask_ratio) as fp32
-    [N*Do*Ho*Wo] vectors and the output dims.  No gradient (constants)."""
+    [N*Do*Ho*Wo] vectors and the output dims.  No gradient (constants).  planar: the 2-D PartialConv2d on n*d
+    independent images (k x k window, depth untouched)."""
     d, h, w = dims
     do, ho, wo = ((x + 2 * pad - k) // stride + 1 for x in (d, h, w))
+    if planar:
+        do = d
     assert len(rows) <= 2 and (full is not None or rows)
     dev = full.device if full is not None else rows[0].rows.device
     upd = torch.empty(n * do * ho * wo, dtype=torch.float32, device=dev)
@@ -722,7 +725,7 @@ def mask_window(n, dims, k, stride, pad, eps, full=None, full_channels=0, rows=(
         full = nhwc(full)
         assert tuple(full.shape[:3]) == (n * d, h, w)
     L.call("bg_mask_window", L.dt(full.dtype) if full is not None else 0, L.ptr(full), 0 if full is None else ld_of(full),
-           full_channels, r[0][0], r[0][1], r[1][0], r[1][1], n, d, h, w, do, ho, wo, k, stride, pad, float(eps),
+           full_channels, r[0][0], r[0][1], r[1][0], r[1][1], n, d, h, w, do, ho, wo, k, stride, pad, int(planar), float(eps),
            upd.data_ptr(), ratio.data_ptr())
     return upd, ratio, (do, ho, wo)
 
@@ -843,12 +846,13 @@ class NearestResize3dFn(torch.autograd.Function):
 
 class TVLossCompFn(torch.autograd.Function):
     """total_variation_loss(mask*input + (1-mask)*output) of InpaintingLoss (utils/losses.py:40-44,71,97) on
-    contiguous fp32 [N,C,D,H,W] tensors; differentiable w.r.t. `output`."""
+    contiguous fp32 [N,C,D,H,W] tensors (shifts along H and D, as the reference's 4-D function acts on them) or
+    [N,C,H,W] ones (shifts along W and H: the same kernel on the view [N,C,H,W,1]); differentiable w.r.t. `output`."""
 
     @staticmethod
     def forward(ctx, output, inp, mask):
         o, i_, m = (t.contiguous().float() for t in (output, inp, mask))
-        n, c, d, h, w = o.shape
+        n, c, d, h, w = o.shape if o.dim() == 5 else (*o.shape, 1)
         comp = torch.empty_like(o)
         L.call("bg_blend_f32", m.data_ptr(), i_.data_ptr(), o.data_ptr(), comp.data_ptr(), o.numel())
         loss = _f32(1, device=o.device)

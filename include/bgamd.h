@@ -159,6 +159,8 @@ int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int3
  *   sum runs over up to three segments of input channels: `mask` (a per-channel tensor, may be NULL) and rows0 /
  *   rows1 (fp32 [N*D*H*W], may be NULL): per-pixel masks standing for c0 / c1 identical channels -- what every
  *   update_mask is (its Cout channels are equal) -- so past the first layer no Cout-channel mask tensor exists.
+ *   planar != 0: PartialConv2d (architecture/common/partialconv2d.py:49-75) on N*D independent images -- the
+ *   window is k x k, the depth axis is not windowed (Do == D), winsize = C*k^2.
  * bg_resize_nearest3d_rows: the nearest resize of such a per-pixel mask.
  * bg_mul_rows:   y = x * m (element-wise; input * mask_in, partialconv3d.py:77).
  * bg_scale_rows: y[r,c] = (x ? x[r,c] : 1) * s[r] + (bias ? bias[c] * t[r] : 0): raw_out * mask_ratio, the bias form
@@ -172,7 +174,7 @@ int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int3
  * ------------------------------------------------------------------------- */
 int bg_mask_window(int32_t dtype, const void* mask, int32_t ld, int32_t C, const float* rows0, int32_t c0, const float* rows1,
                    int32_t c1, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Do, int32_t Ho, int32_t Wo, int32_t k,
-                   int32_t stride, int32_t pad, float eps, float* update_mask, float* ratio, void* stream);
+                   int32_t stride, int32_t pad, int32_t planar, float eps, float* update_mask, float* ratio, void* stream);
 int bg_resize_nearest3d_rows(const float* x, float* y, int32_t N, int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho,
                              int32_t Wo, void* stream);
 int bg_mul_rows(int32_t dtype, const void* x, int32_t ldx, const void* m, int32_t ldm, void* y, int32_t ldy, int64_t rows,

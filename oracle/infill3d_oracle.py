@@ -55,6 +55,36 @@ def unet3d_spec(cin: int, cout: int, layer_size: int = 7, norm_kind: str = "batc
     return s
 
 
+def unet2d_spec(cin: int, cout: int, layer_size: int = 7, norm_kind: str = "batch"):
+    """state_dict entries of the 2-D PConvUNet in registration order (infill.py:140-163); kernels are [.,.,k,k]."""
+    s = []
+    for key, shape, role in unet3d_spec(cin, cout, layer_size, norm_kind):
+        if key.startswith("last_conv"):
+            continue
+        if key == "dec_1.conv.weight":          # 64 + output_channels (infill.py:158)
+            shape = (32, 64 + cout) + shape[2:]
+        s.append((key, shape[:-1] if role == "conv" else shape, role))
+    s += [(k_, sh[:-1] if r == "conv" else sh, r) for k_, sh, r in _pcb_entries("input_enc_1", cin, 64, 1, norm_kind)]
+    s += [(k_, sh[:-1] if r == "conv" else sh, r) for k_, sh, r in _pcb_entries("last_conv", 64 + 32, cout, 1, None, bias=True)]
+    return s
+
+
+def unet2d(P: State, x, mask, layer_size: int, ctx: NormCtx):
+    """2-D PConvUNet.forward (infill.py:165-210), upsampling_mode='nearest'."""
+    hs, ms = {0: x}, {0: mask}
+    for i in range(1, layer_size + 1):
+        hs[i], ms[i] = pcb_activ(P, f"enc_{i}", hs[i - 1], ms[i - 1], 3, 2, 1, i != 1, "relu", ctx)
+    h, m = hs[layer_size], ms[layer_size]
+    for i in range(layer_size, 0, -1):
+        size = tuple(hs[i - 1].shape[2:])
+        h = F.interpolate(h, size=size, mode="nearest")
+        m = F.interpolate(m, size=size, mode="nearest")
+        h, m = pcb_activ(P, f"dec_{i}", torch.cat([h, hs[i - 1]], dim=1), torch.cat([m, ms[i - 1]], dim=1), 3, 1, 1, True,
+                         "leaky", ctx)
+    hin, hin_mask = pcb_activ(P, "input_enc_1", x, mask, 1, 1, 0, True, "leaky", ctx)
+    return pcb_activ(P, "last_conv", torch.cat([h, hin], dim=1), torch.cat([m, hin_mask], dim=1), 1, 1, 0, False, None, ctx)
+
+
 def disc3d_spec(cin: int, layer_size: int = 7, norm_kind: str = "batch"):
     """state_dict entries of infill3d_gan.Discriminator (infill3d_gan.py:17-30)."""
     s = []
@@ -66,17 +96,19 @@ def disc3d_spec(cin: int, layer_size: int = 7, norm_kind: str = "batch"):
 
 
 def partial_conv3d(x, mask, w, b, stride, pad):
-    """PartialConv3d.forward with multi_channel=True, return_mask=True (partialconv3d.py:49-92)."""
-    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    """PartialConv3d.forward with multi_channel=True, return_mask=True (partialconv3d.py:49-92); with a 4-D weight
+    the same function is PartialConv2d.forward (partialconv2d.py:49-89), which differs in the rank only."""
+    cout, cin, k, nd = w.shape[0], w.shape[1], w.shape[2], w.dim() - 2
+    conv = F.conv3d if nd == 3 else F.conv2d
     with torch.no_grad():
-        ones = torch.ones(1, cin, k, k, k, dtype=mask.dtype)
-        upd = F.conv3d(mask, ones, None, stride, pad).expand(-1, cout, -1, -1, -1)   # identical for every output channel
-        ratio = float(cin * k ** 3) / (upd + PC_EPS)
+        ones = torch.ones((1, cin) + (k,) * nd, dtype=mask.dtype)
+        upd = conv(mask, ones, None, stride, pad).expand(-1, cout, *([-1] * nd))   # identical for every output channel
+        ratio = float(cin * k ** nd) / (upd + PC_EPS)
         upd = torch.clamp(upd, 0, 1)
         ratio = ratio * upd
-    raw = F.conv3d(x * mask, w, b, stride, pad)
+    raw = conv(x * mask, w, b, stride, pad)
     if b is not None:
-        bv = b.view(1, -1, 1, 1, 1)
+        bv = b.view((1, -1) + (1,) * nd)
         out = ((raw - bv) * ratio + bv) * upd
     else:
         out = raw * ratio
@@ -123,7 +155,8 @@ def disc3d(P: State, x, mask, layer_size: int, ctx: NormCtx):
 
 
 def total_variation_loss(image):
-    """utils/losses.py:40-44, applied as written to a 5-D tensor: shifts along dims 3 and 2."""
+    """utils/losses.py:40-44, applied as written: shifts along dims 3 and 2 (W and H of a 4-D image batch; H and D of
+    a 5-D volume batch)."""
     return (image[:, :, :, :-1] - image[:, :, :, 1:]).abs().mean() + (image[:, :, :-1, :] - image[:, :, 1:, :]).abs().mean()
 
 

@@ -45,6 +45,7 @@ from oracle import gan3d_oracle as orc3  # noqa: E402
 from oracle import infill3d_oracle as orci  # noqa: E402
 sys.path.insert(0, "/root/reference/src/deepCam/architecture/gpsro")
 from architecture.gpsro import infill3d_gan as ref_infill  # noqa: E402
+from architecture.gpsro import infill as ref_infill2d  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -568,10 +569,45 @@ def golden_infill_trajectory(d=32, h=24, w=40, n=2, g_layers=4, d_layers=5, step
              field_seed0=2000, noise_seed0=3000, loss_type="l2")), **out)
 
 
+def golden_infill2d(c=2, h=40, w=56, n=2, layers=4):
+    """2-D partial-convolution U-Net (infill.py, partialconv2d.py; SURVEY 8(f)-4 "2-D shapes") + the inpainting loss on
+    4-D tensors (its total-variation term then shifts along W and H)."""
+    res = {}
+    g = ref_infill2d.PConvUNet(layer_size=layers, input_channels=c, output_channels=c, upsampling_mode="nearest",
+                               normalizer=nn.BatchNorm2d)
+    spec = orci.unet2d_spec(c, c, layers)
+    _load_checked(g, spec, 71)
+    g.train()
+    gen = torch.Generator().manual_seed(171)
+    gt = torch.randn((n, c, h, w), generator=gen)
+    mask = (torch.rand((n, c, h, w), generator=gen) > 0.3).float()
+    x = gt * mask
+    out, out_mask = g(x, mask)
+    ld = ref_losses.InpaintingLoss(loss_type="l1")(x, out, gt, mask)
+    (6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]).backward()
+    res["out"], res["out_mask"] = out.detach().numpy(), out_mask.detach().numpy()
+    for k_ in ("hole", "valid", "tv"):
+        res["loss_" + k_] = np.array(ld[k_].item())
+    cs = checksums((k, p.grad) for k, p in g.named_parameters())
+    res["grad_keys"], res["grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+    named = dict(g.named_parameters())
+    for k in ("enc_1.conv.weight", "dec_1.conv.weight", "input_enc_1.conv.weight", "input_enc_1.bn.weight",
+              "last_conv.conv.weight", "last_conv.conv.bias"):
+        res["grad::" + k] = named[k].grad.numpy()
+    sd = g.state_dict()
+    for k in ("enc_2.bn.running_mean", "input_enc_1.bn.running_var"):
+        res["buf::" + k] = sd[k].numpy()
+    np.savez_compressed(os.path.join(HERE, f"infill2d_c{c}_{h}x{w}.npz"),
+                        meta=json.dumps(dict(c=c, h=h, w=w, n=n, layers=layers, seed=71, field_seed=171)), **res)
+    print("infill2d goldens written:", {k_: float(res["loss_" + k_]) for k_ in ("hole", "valid", "tv")})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     if "all" in which or "infill3d" in which:
         golden_infill3d()
+    if "all" in which or "infill2d" in which:
+        golden_infill2d()
     if "all" in which or "infill3d_trajectory" in which:
         golden_infill_trajectory()
     if "all" in which or "gan3d" in which:

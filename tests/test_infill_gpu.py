@@ -272,3 +272,41 @@ def test_infill_gan_loop_vs_reference_trajectory(golden_dir):
         close(D.state_dict()["enc_2.bn.running_var"].cpu(), torch.from_numpy(z["D::enc_2.bn.running_var"][s]), 10 * tol, "D rv")
         assert int(G.state_dict()["enc_2.bn.num_batches_tracked"]) == 2 * (s + 1)
         assert int(D.state_dict()["enc_2.bn.num_batches_tracked"]) == 3 * (s + 1)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_unet2d_vs_reference_golden(golden_dir, dtype):
+    """2-D PConvUNet / PartialConv2d (SURVEY 8(f)-4 "2-D shapes"): the planar mask window, masks bit-exact, the
+    inpainting loss on 4-D tensors (total variation along W and H)."""
+    from bias_gan_amd.architecture.gpsro import infill as i2
+    z = np.load(os.path.join(golden_dir, "infill2d_c2_40x56.npz"))
+    m = json.loads(str(z["meta"]))
+    G = i2.PConvUNet(layer_size=m["layers"], input_channels=m["c"], output_channels=m["c"], normalizer=nn.BatchNorm2d,
+                     compute_dtype=dtype)
+    G.load_state_dict(oi.fill_state(oi.unet2d_spec(m["c"], m["c"], m["layers"]), m["seed"]))
+    G.to(DEV).train()
+    gen = torch.Generator().manual_seed(m["field_seed"])
+    gt = torch.randn((m["n"], m["c"], m["h"], m["w"]), generator=gen)
+    mask = (torch.rand((m["n"], m["c"], m["h"], m["w"]), generator=gen) > 0.3).float()
+    x = gt * mask
+    out, out_mask = G(x.to(DEV), mask.to(DEV))
+    assert np.array_equal(out_mask.cpu().numpy(), z["out_mask"])
+    r = rms(out.detach().cpu(), z["out"])
+    print(f"unet2d {dtype}: fwd rms-rel {r:.2e}")
+    if dtype == F32:
+        close(out.detach().cpu(), torch.from_numpy(z["out"]), 5e-5, "out")
+    else:
+        assert r <= 1e-1
+    ld = ig.InpaintingLoss("l1")(x.to(DEV), out, gt.to(DEV), mask.to(DEV))
+    for k in ("hole", "valid", "tv"):
+        assert abs(ld[k].item() - float(z["loss_" + k])) <= (1e-4 if dtype == F32 else 5e-2) * float(z["loss_" + k]), k
+    (6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]).backward()
+    torch.cuda.synchronize()
+    named = dict(G.named_parameters())
+    worst = max(rms(named[k[6:]].grad.cpu(), z[k]) for k in z.files if k.startswith("grad::"))
+    print(f"unet2d {dtype}: selected gradients worst rms-rel {worst:.2e}")
+    assert worst <= (2e-3 if dtype == F32 else 3e-1)
+    sd = G.state_dict()
+    for k in z.files:
+        if k.startswith("buf::"):
+            close(sd[k[5:]].cpu(), torch.from_numpy(z[k]), 1e-4 if dtype == F32 else 5e-2, k)

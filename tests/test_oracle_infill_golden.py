@@ -125,3 +125,39 @@ def test_oracle_loop_matches_reference_trajectory(golden_dir):
         assert int(st.PG["enc_2.bn.num_batches_tracked"]) == int(z["G::nbt"][s]) == 2 * (s + 1)
         assert int(st.PD["enc_2.bn.num_batches_tracked"]) == int(z["D::nbt"][s]) == 3 * (s + 1)
     assert seen == {(True, False), (True, True), (False, True)}
+
+
+def _fields2d(m):
+    gen = torch.Generator().manual_seed(m["field_seed"])
+    gt = torch.randn((m["n"], m["c"], m["h"], m["w"]), generator=gen)
+    mask = (torch.rand((m["n"], m["c"], m["h"], m["w"]), generator=gen) > 0.3).float()
+    return gt * mask, gt, mask
+
+
+def test_unet2d(golden_dir):
+    """The 2-D PConvUNet (infill.py) and PartialConv2d against vectors from the reference's modules
+    (tests/golden/infill2d_c2_40x56.npz; make_golden.py infill2d)."""
+    z = np.load(os.path.join(golden_dir, "infill2d_c2_40x56.npz"))
+    m = json.loads(str(z["meta"]))
+    spec = oi.unet2d_spec(m["c"], m["c"], m["layers"])
+    P = oi.fill_state(spec, m["seed"])
+    keys = oi.trainable_keys(spec)
+    for k in keys:
+        P[k].requires_grad_(True)
+    x, gt, mask = _fields2d(m)
+    out, out_mask = oi.unet2d(P, x, mask, m["layers"], oi.NormCtx("batch", True))
+    _close(out.detach().numpy(), z["out"], what="out")
+    assert np.array_equal(out_mask.numpy(), z["out_mask"])
+    ld = oi.inpainting_loss(x, out, gt, mask, "l1")
+    for k in ("hole", "valid", "tv"):
+        _close(ld[k].item(), z["loss_" + k], what=k)
+    (6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]).backward()
+    ref = dict(zip([str(k) for k in z["grad_keys"]], z["grad_cs"]))
+    assert list(ref.keys()) == keys
+    for k in keys:
+        assert abs(_cs(P[k].grad)[2] - ref[k][2]) <= 1e-3 * ref[k][2] + 1e-12, k
+    for k in z.files:
+        if k.startswith("grad::"):
+            _close(P[k[6:]].grad.numpy(), z[k], rtol=5e-4, what=k)
+        if k.startswith("buf::"):
+            _close(P[k[5:]].numpy(), z[k], what=k)
