@@ -80,6 +80,7 @@ _SIGS = {
     "bg_dwconv3x3x3_bwd_weight": [C.POINTER(Dw3Desc), c_vp, c_vp, c_vp, c_vp],
     "bg_depth_resize_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_depth_resize_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_depth_avg2": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_mask_window": [c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],
     "bg_resize_nearest3d_rows": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

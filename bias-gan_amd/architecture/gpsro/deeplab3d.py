@@ -317,8 +317,125 @@ class InterpolationUpsampler(BGModule):
         return ops.resize_trilinear(x, n, D, H, W, torch.float32)   # fp32: generator output / loss input
 
 
+class ConvTranspose3d(BGModule):
+    """nn.ConvTranspose3d(groups=1, bias=False) parameter container (weight [Cin, Cout, k, k, k]).  The arena stores it
+    as the dense 3-D convolution it is the adjoint of; forward = that convolution's data gradient: the 2-D
+    data-gradient GEMM over the KD*C channel blocks, then the depth fold."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=(0, 0, 0), bias=False):
+        super().__init__()
+        assert not bias, "the transposed convolutions on this path have no bias"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (kernel_size,) * 3
+        self.stride, self.padding = (stride,) * 3, (padding,) * 3
+        self.output_padding = tuple(output_padding) if not isinstance(output_padding, int) else (output_padding,) * 3
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, kernel_size, kernel_size, kernel_size))
+        self.bias = None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self._bg_param_layout = {"weight": _conv3d_layout}
+
+    def forward(self, x, n):
+        a = self.arena()
+        ws = a.by_param[id(self.weight)]
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        y = ops.ConvTranspose2dFn.apply(x, self.weight, a, ws, s, p, self.output_padding[1:])
+        d = x.shape[0] // n
+        return ops.DepthFoldFn.apply(y, n, k, s, p, 1, (d - 1) * s - 2 * p + k + self.output_padding[0])
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size[0]}, s={self.stride[0]}, op={self.output_padding}"
+
+
+def _norm_pool_act3d(owner: BGModule, m: nn.Module, pool: nn.Module, x, n):
+    """normalizer -> nnpooler -> LeakyReLU(0.2), the tail of every 3-D Deconv unit (deeplab3d.py:351-354)."""
+    if isinstance(pool, nn.AvgPool3d):
+        p = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+        return ops.leaky_relu(ops.avgpool3d_2(apply_norm3d(owner, m, x, n, act=False), n, p))
+    return apply_norm3d(owner, m, x, n, act=True)   # nn_pooling=False: nn.Identity in its place
+
+
+def _deconv3d_init(mod: nn.Module):
+    # DeconvUpsampler / DeconvUpsamplerExtension.__init_weight (deeplab3d.py:397-414,446-463): the same normal fill for
+    # Conv3d and ConvTranspose3d, n = k0 * k1 * out_channels
+    gain = nn.init.calculate_gain("leaky_relu", 0.2)
+    for m in mod.modules():
+        if isinstance(m, (Conv3d, ConvTranspose3d)):
+            nn.init.normal_(m.weight, mean=0.0, std=gain / math.sqrt(m.kernel_size[0] * m.kernel_size[1] * m.out_channels))
+
+
+class DeconvUpsampler(BGModule):
+    """Four stride-2 transposed 3-D convolutions, each followed by normaliser -> AvgPool3d(2, 1) -> LeakyReLU, around
+    the trilinear match to the skip, the concat and the 3x3x3 / 3x3x3 / 1x1x1 stack (deeplab3d.py:342-395).
+    Shape-locked by the output paddings to D = 4a-3, H = 4b-1, W = 4c-3 once DeepLab3d's final pool is applied
+    (45 x 19 x 37: the GPS-RO grid)."""
+
+    def __init__(self, n_output, normalizer=nn.BatchNorm3d, nn_pooling=True):
+        super().__init__()
+        pooler = nn.AvgPool3d if nn_pooling else (lambda *a, **k: nn.Identity())
+
+        def unit(cin, cout, op):
+            return nn.Sequential(ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=op, bias=False),
+                                 normalizer(cout), pooler(2, stride=1, padding=0), nn.LeakyReLU(0.2, inplace=True))
+        self.deconv1 = unit(256, 256, (1, 1, 1))
+        self.deconv2 = unit(256, 256, (1, 1, 1))
+        self.conv1 = nn.Sequential(Conv3d(304, 256, 3, stride=1, padding=1, bias=False), normalizer(256),
+                                   nn.LeakyReLU(0.2, inplace=True),
+                                   Conv3d(256, 256, 3, stride=1, padding=1, bias=False), normalizer(256),
+                                   nn.LeakyReLU(0.2, inplace=True), Conv3d(256, 256, 1, stride=1))
+        self.deconv3 = unit(256, 128, (0, 1, 0))
+        self.last_deconv = nn.Sequential(ConvTranspose3d(128, n_output, 3, stride=2, padding=1, output_padding=(1, 1, 1),
+                                                         bias=False))
+        _deconv3d_init(self)
+
+    def _unit(self, seq, x, n):
+        return _norm_pool_act3d(self, seq[1], seq[2], seq[0](x, n), n)
+
+    def forward(self, x, low_level_features, n, size):
+        x = self._unit(self.deconv1, x, n)
+        x = self._unit(self.deconv2, x, n)
+        low = low_level_features
+        x = ops.resize_trilinear(x, n, low.shape[0] // n, low.shape[1], low.shape[2])    # "add a matching layer"
+        x = ops.concat(x, low)
+        c1 = self.conv1
+        x = conv_norm3d(self, c1[0], c1[1], x, n, act=True)
+        x = conv_norm3d(self, c1[3], c1[4], x, n, act=True)
+        x = c1[6](x, n)
+        x = self._unit(self.deconv3, x, n)
+        return self.last_deconv[0](x, n)
+
+
+class DeconvUpsamplerExtension(BGModule):
+    """Full-resolution stem on the raw input + normalised decoder output -> 3x3x3 / 3x3x3 to n_output
+    (deeplab3d.py:417-444)."""
+
+    def __init__(self, n_input, n_output, normalizer=nn.BatchNorm3d, nn_pooling=True):
+        super().__init__()
+        pooler = nn.AvgPool3d if nn_pooling else (lambda *a, **k: nn.Identity())
+        self.init_norm = nn.Sequential(normalizer(128), pooler(2, stride=1, padding=1), nn.LeakyReLU(0.2, inplace=True))
+        self.conv1 = nn.Sequential(Conv3d(n_input, 64, 3, stride=1, padding=1, bias=False), normalizer(64),
+                                   nn.LeakyReLU(0.2, inplace=True),
+                                   Conv3d(64, 128, 3, stride=1, padding=1, bias=False), normalizer(128),
+                                   nn.LeakyReLU(0.2, inplace=True))
+        self.conv2 = nn.Sequential(Conv3d(256, 64, 3, stride=1, padding=1, bias=False), normalizer(64),
+                                   nn.LeakyReLU(0.2, inplace=True),
+                                   Conv3d(64, n_output, 3, stride=1, padding=1, bias=False))
+        _deconv3d_init(self)
+
+    def forward(self, input, x, n):
+        c1, c2 = self.conv1, self.conv2
+        skip = conv_norm3d(self, c1[0], c1[1], input, n, act=True)
+        skip = conv_norm3d(self, c1[3], c1[4], skip, n, act=True)
+        x = _norm_pool_act3d(self, self.init_norm[0], self.init_norm[1], x, n)
+        if tuple(x.shape[:3]) != tuple(skip.shape[:3]):
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: the 3-D Deconv upsampler needs "
+                               "D = 4a-3, H = 4b-1, W = 4c-3 inputs")
+        x = ops.concat(x, skip)
+        x = conv_norm3d(self, c2[0], c2[1], x, n, act=True)
+        return c2[3](x, n)
+
+
 class DeepLab3d(BGModule):
-    """Encoder-ASPP-decoder in 3-D (deeplab3d.py:468-566), Interpolate upsampler."""
+    """Encoder-ASPP-decoder in 3-D (deeplab3d.py:468-566)."""
 
     def __init__(self, n_input=3, n_output=21, os=16, upsampler_type="Deconv", pretrained=False, _print=True,
                  normalizer=nn.BatchNorm3d, nn_pooling=True):
@@ -351,10 +468,14 @@ class DeepLab3d(BGModule):
         if self.upsampler_type == "Interpolate":
             self.upsample = InterpolationUpsampler(n_output, normalizer)
         elif self.upsampler_type.startswith("Deconv"):
-            raise NotImplementedError("the 3-D Deconv upsamplers (ConvTranspose3d chain, deeplab3d.py:342-466) are not "
-                                      "built on the HIP path; use upsampler_type='Interpolate'")
+            self.upsample = DeconvUpsampler(n_output=128 if self.upsampler_type == "Deconv1x" else n_output,
+                                            normalizer=normalizer, nn_pooling=nn_pooling)
         else:
             raise NotImplementedError("Error, upsampler {} not implemented.".format(upsampler_type))
+        if self.upsampler_type == "Deconv1x":
+            self.upsample_extension = DeconvUpsamplerExtension(n_input, n_output, normalizer, nn_pooling)
+        elif self.upsampler_type == "Deconv":
+            self.final_pool = nn.AvgPool3d(2, stride=1, padding=1) if nn_pooling else nn.Identity()
 
     def forward(self, input):
         """NCDHW fp32 [N, n_input, D, H, W] -> NCDHW fp32 [N, n_output, D, H, W]."""
@@ -372,6 +493,10 @@ class DeepLab3d(BGModule):
         x = conv_norm3d(self, self.conv1, self.bn1, x, n, act=True)
         low = conv_norm3d(self, self.conv2, self.bn2, low, n, act=True)
         y = self.upsample(x, low, n, (D, H, W))
+        if self.upsampler_type == "Deconv1x":
+            y = self.upsample_extension(xi, y, n)
+        elif self.upsampler_type == "Deconv" and isinstance(self.final_pool, nn.AvgPool3d):
+            y = ops.avgpool3d_2(y, n, 1)
         return from_folded(y, n, self.n_output)
 
     def freeze_bn(self):

@@ -334,6 +334,41 @@ int check_dw3(const bg_dwconv3d_desc* d, const char* who) {
     return BG_OK;
 }
 
+
+// Depth half of nn.AvgPool3d(2, stride 1) (the 2 x 2 in-plane half is bg_avgpool2x2): y[n, od] = 0.5 * (x[n, od + off]
+// + x[n, od + off + 1]), zero outside the volume (count_include_pad).  off = -padding is the forward pass,
+// off = padding - 1 with the roles of x and y exchanged its adjoint.
+template <typename T>
+__global__ __launch_bounds__(256) void depth_avg2_kernel(const T* x, int ldx, T* y, int ldy, int N, int Di, int Do, int HW, int C,
+                                                         int off) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long total = (long long)N * Do * HW * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / cv;
+        const int c = (int)(i - pix * cv) * VEC;
+        const int p = (int)(pix % HW);
+        const long long sl = pix / HW;
+        const int od = (int)(sl % Do), n = (int)(sl / Do);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int id = od + off + t;
+            if ((unsigned)id >= (unsigned)Di) continue;
+            Chunk<T> v;
+            v.load(x + (((long long)n * Di + id) * HW + p) * ldx + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += v.get(e);
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, 0.5f * acc[e]);
+        o.store(y + pix * ldy + c);
+    }
+}
+
 }  // namespace
 
 extern "C" int bg_depth_unfold(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t D,
@@ -448,5 +483,18 @@ extern "C" int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const voi
     BG_DISPATCH2(dy_dtype, dx_dtype, TI, TO,
                  hipLaunchKernelGGL((depth_resize_bwd_kernel<TI, TO>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("depth_resize_bwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_depth_avg2(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Di, int32_t Do,
+                             int32_t HW, int32_t C, int32_t off, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && x && y && aligned16(x) && aligned16(y) && N > 0 && Di > 0 && Do > 0 && HW > 0 && C > 0,
+                 "bg_depth_avg2: bad args");
+    const int vec = dtype_vec(dtype);
+    BG_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0 && ldx >= C && ldy >= C, "bg_depth_avg2: C/ld must be multiples of %d", vec);
+    const long long total = (long long)N * Do * HW * (C / vec);
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((depth_avg2_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, ldx, (T*)y, ldy, N, Di, Do, HW, C, off));
+    BG_CHECK_LAUNCH("depth_avg2_kernel");
     return BG_OK;
 }

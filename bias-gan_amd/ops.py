@@ -626,6 +626,60 @@ class DepthUnfoldFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class DepthFoldFn(torch.autograd.Function):
+    """Adjoint of DepthUnfoldFn as a forward op: [N*Dk,H,W,KD*C] -> [N*D,H,W,C], slice id of the result collects
+    channel block kd of every slice od with od*stride - pad + kd*dil == id.  The depth half of nn.ConvTranspose3d
+    (its in-plane half is ConvTranspose2dFn over the KD*C channels)."""
+
+    @staticmethod
+    def forward(ctx, x, n, kd, stride, pad, dil, d):
+        x = nhwc(x)
+        ndk, h, w, kc = x.shape
+        dk, c = ndk // n, kc // kd
+        assert (d + 2 * pad - dil * (kd - 1) - 1) // stride + 1 == dk, "bad output depth for this fold"
+        y = new_act(n * d, h, w, c, x.dtype, x.device)
+        L.call("bg_depth_fold", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, d, dk, h * w, c, kd, stride, pad, dil)
+        ctx.meta = (n, d, dk, h, w, c, kd, stride, pad, dil, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, d, dk, h, w, c, kd, stride, pad, dil, dtype = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n * dk, h, w, kd * c, dtype, g.device)
+        L.call("bg_depth_unfold", L.dt(dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, d, dk, h * w, c, kd, stride,
+               pad, dil)
+        return dx, None, None, None, None, None, None
+
+
+class DepthAvg2Fn(torch.autograd.Function):
+    """Depth half of nn.AvgPool3d(2, stride=1, padding=p), p in {0, 1}: [N*D,H,W,C] -> [N*(D+2p-1),H,W,C]."""
+
+    @staticmethod
+    def forward(ctx, x, n, p: int):
+        x = nhwc(x)
+        nd, h, w, c = x.shape
+        d = nd // n
+        do = d + 2 * p - 1
+        y = new_act(n * do, h, w, c, x.dtype, x.device)
+        L.call("bg_depth_avg2", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, d, do, h * w, c, -p)
+        ctx.meta = (n, d, do, h, w, c, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, d, do, h, w, c, p = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n * d, h, w, c, g.dtype, g.device)
+        L.call("bg_depth_avg2", L.dt(g.dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, do, d, h * w, c, p - 1)
+        return dx, None, None
+
+
+def avgpool3d_2(x, n, p: int):
+    """nn.AvgPool3d(2, stride=1, padding=p) on a folded volume: the mean of 8 is the depth pair mean of 2 x 2 means."""
+    return avgpool2x2(DepthAvg2Fn.apply(x, n, int(p)), int(p))
+
+
 class DwConv3dFn(torch.autograd.Function):
     """Depthwise 3x3x3 of SeparableConv3d_same with fixed_padding folded in (bg_dwconv3x3x3_*)."""
 

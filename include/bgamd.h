@@ -146,6 +146,11 @@ int bg_depth_resize_fwd(int32_t in_dtype, int32_t out_dtype, const void* x, int3
                         int32_t Di, int32_t Do, int32_t HW, int32_t C, void* stream);
 int bg_depth_resize_bwd(int32_t dy_dtype, int32_t dx_dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N,
                         int32_t Di, int32_t Do, int32_t HW, int32_t C, void* stream);
+/* Depth half of nn.AvgPool3d(2, stride=1, padding=p) of the 3-D Deconv upsamplers (deeplab3d.py:349-386,436,527; the
+ * in-plane half is bg_avgpool2x2): y[n,od] = 0.5 * (x[n,od+off] + x[n,od+off+1]), zeros outside (count_include_pad).
+ * off = -p: forward (Do = Di + 2p - 1); off = p - 1 with x := dy, y := dx: the adjoint. */
+int bg_depth_avg2(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Di, int32_t Do, int32_t HW,
+                  int32_t C, int32_t off, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Partial-convolution U-Net GAN (architecture/common/partialconv3d.py,

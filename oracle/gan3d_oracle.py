@@ -72,8 +72,8 @@ def xception3d_spec(prefix: str, cin: int, norm_kind: str, os: int = 16):
     return s
 
 
-def deeplab3d_spec(prefix: str, cin: int, cout: int, norm_kind: str, os: int = 16):
-    """DeepLab3d with the Interpolate upsampler (deeplab3d.py:468-520, 301-312)."""
+def deeplab3d_spec(prefix: str, cin: int, cout: int, norm_kind: str, os: int = 16, upsampler: str = "Interpolate"):
+    """DeepLab3d (deeplab3d.py:468-532) with the Interpolate (:301-312), Deconv or Deconv1x (:342-444) upsampler."""
     s = xception3d_spec(prefix + "xception_features.", cin, norm_kind, os)
     for i in (1, 2, 3, 4):
         k = 1 if i == 1 else 3
@@ -85,19 +85,48 @@ def deeplab3d_spec(prefix: str, cin: int, cout: int, norm_kind: str, os: int = 1
     s += _norm_entries(prefix + "bn1", 256, norm_kind)
     s.append((prefix + "conv2.weight", (48, 128, 1, 1, 1), "conv"))
     s += _norm_entries(prefix + "bn2", 48, norm_kind)
-    up = prefix + "upsample.last_conv."
-    s.append((up + "0.weight", (256, 304, 3, 3, 3), "conv"))
-    s += _norm_entries(up + "1", 256, norm_kind)
-    s.append((up + "3.weight", (256, 256, 3, 3, 3), "conv"))
-    s += _norm_entries(up + "4", 256, norm_kind)
-    s.append((up + "6.weight", (cout, 256, 1, 1, 1), "conv"))
-    s.append((up + "6.bias", (cout,), "bias"))
+    if upsampler == "Interpolate":
+        up = prefix + "upsample.last_conv."
+        s.append((up + "0.weight", (256, 304, 3, 3, 3), "conv"))
+        s += _norm_entries(up + "1", 256, norm_kind)
+        s.append((up + "3.weight", (256, 256, 3, 3, 3), "conv"))
+        s += _norm_entries(up + "4", 256, norm_kind)
+        s.append((up + "6.weight", (cout, 256, 1, 1, 1), "conv"))
+        s.append((up + "6.bias", (cout,), "bias"))
+        return s
+    assert upsampler in ("Deconv", "Deconv1x"), upsampler
+    n_up = 128 if upsampler == "Deconv1x" else cout
+    up, k3 = prefix + "upsample.", (3, 3, 3)
+    # nn.ConvTranspose3d weights are [Cin, Cout, k, k, k]
+    s.append((up + "deconv1.0.weight", (256, 256) + k3, "conv"))
+    s += _norm_entries(up + "deconv1.1", 256, norm_kind)
+    s.append((up + "deconv2.0.weight", (256, 256) + k3, "conv"))
+    s += _norm_entries(up + "deconv2.1", 256, norm_kind)
+    s.append((up + "conv1.0.weight", (256, 304) + k3, "conv"))
+    s += _norm_entries(up + "conv1.1", 256, norm_kind)
+    s.append((up + "conv1.3.weight", (256, 256) + k3, "conv"))
+    s += _norm_entries(up + "conv1.4", 256, norm_kind)
+    s.append((up + "conv1.6.weight", (256, 256, 1, 1, 1), "conv"))
+    s.append((up + "conv1.6.bias", (256,), "bias"))
+    s.append((up + "deconv3.0.weight", (256, 128) + k3, "conv"))
+    s += _norm_entries(up + "deconv3.1", 128, norm_kind)
+    s.append((up + "last_deconv.0.weight", (128, n_up) + k3, "conv"))
+    if upsampler == "Deconv1x":
+        ex = prefix + "upsample_extension."
+        s += _norm_entries(ex + "init_norm.0", 128, norm_kind)
+        s.append((ex + "conv1.0.weight", (64, cin) + k3, "conv"))
+        s += _norm_entries(ex + "conv1.1", 64, norm_kind)
+        s.append((ex + "conv1.3.weight", (128, 64) + k3, "conv"))
+        s += _norm_entries(ex + "conv1.4", 128, norm_kind)
+        s.append((ex + "conv2.0.weight", (64, 256) + k3, "conv"))
+        s += _norm_entries(ex + "conv2.1", 64, norm_kind)
+        s.append((ex + "conv2.3.weight", (cout, 64) + k3, "conv"))
     return s
 
 
-def generator3d_spec(cin: int, cout: int, noise_dims: int, norm_kind: str, os: int = 16):
+def generator3d_spec(cin: int, cout: int, noise_dims: int, norm_kind: str, os: int = 16, upsampler: str = "Interpolate"):
     """Generator = noise concat + DeepLab3d under 'model.' (deeplab3d_gan.py:69-100)."""
-    return deeplab3d_spec("model.", cin + noise_dims, cout, norm_kind, os)
+    return deeplab3d_spec("model.", cin + noise_dims, cout, norm_kind, os, upsampler)
 
 
 def discriminator3d_spec(cin: int, norm_kind: str, os: int = 16):
@@ -178,8 +207,44 @@ def trilinear_ac(x: torch.Tensor, size) -> torch.Tensor:
     return F.interpolate(x, size=tuple(size), mode="trilinear", align_corners=True)
 
 
+def _deconv3d_unit(P: State, key: str, x: torch.Tensor, ctx: NormCtx, out_pad):
+    """ConvTranspose3d(3, stride 2, pad 1, no bias) -> normaliser -> AvgPool3d(2, 1, 0) -> LeakyReLU (one nn.Sequential
+    of the 3-D DeconvUpsampler, deeplab3d.py:351-354)."""
+    q = ctx.q
+    x = q(F.conv_transpose3d(x, q(P[key + ".0.weight"]), None, 2, 1, out_pad))
+    x = q(norm(P, key + ".1", x, ctx))
+    return q(lrelu(q(F.avg_pool3d(x, 2, 1, 0))))
+
+
+def deconv_upsampler3d(P: State, up: str, x: torch.Tensor, low: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
+    """DeconvUpsampler.forward in 3-D (deeplab3d.py:383-395)."""
+    q = ctx.q
+    x = _deconv3d_unit(P, up + "deconv1", x, ctx, (1, 1, 1))
+    x = _deconv3d_unit(P, up + "deconv2", x, ctx, (1, 1, 1))
+    x = q(trilinear_ac(x, low.shape[2:]))
+    x = torch.cat((x, low), dim=1)
+    x = q(lrelu(norm(P, up + "conv1.1", q(F.conv3d(x, q(P[up + "conv1.0.weight"]), None, 1, 1)), ctx)))
+    x = q(lrelu(norm(P, up + "conv1.4", q(F.conv3d(x, q(P[up + "conv1.3.weight"]), None, 1, 1)), ctx)))
+    x = q(F.conv3d(x, q(P[up + "conv1.6.weight"]), P[up + "conv1.6.bias"]))
+    x = _deconv3d_unit(P, up + "deconv3", x, ctx, (0, 1, 0))
+    return q(F.conv_transpose3d(x, q(P[up + "last_deconv.0.weight"]), None, 2, 1, (1, 1, 1)))
+
+
+def upsampler_extension3d(P: State, ex: str, x_in: torch.Tensor, x: torch.Tensor, ctx: NormCtx) -> torch.Tensor:
+    """DeconvUpsamplerExtension.forward (deeplab3d.py:436-444)."""
+    q = ctx.q
+    skip = q(lrelu(norm(P, ex + "conv1.1", q(F.conv3d(x_in, q(P[ex + "conv1.0.weight"]), None, 1, 1)), ctx)))
+    skip = q(lrelu(norm(P, ex + "conv1.4", q(F.conv3d(skip, q(P[ex + "conv1.3.weight"]), None, 1, 1)), ctx)))
+    x = q(norm(P, ex + "init_norm.0", x, ctx))
+    x = q(lrelu(q(F.avg_pool3d(x, 2, 1, 1))))
+    x = torch.cat((x, skip), dim=1)
+    x = q(lrelu(norm(P, ex + "conv2.1", q(F.conv3d(x, q(P[ex + "conv2.0.weight"]), None, 1, 1)), ctx)))
+    return q(F.conv3d(x, q(P[ex + "conv2.3.weight"]), None, 1, 1))
+
+
 def deeplab3d(P: State, prefix: str, x_in: torch.Tensor, ctx: NormCtx, os: int = 16) -> torch.Tensor:
-    """DeepLab3d.forward with the Interpolate upsampler (deeplab3d.py:534-566, 314-322)."""
+    """DeepLab3d.forward (deeplab3d.py:534-566); the upsampler in use is read off the state's keys: Interpolate
+    (:314-322), Deconv (+ final AvgPool3d(2,1,1), :562-563) or Deconv1x (+ extension)."""
     q = ctx.q
     rates = [1, 6, 12, 18] if os == 16 else [1, 12, 24, 36]
     x, low = xception3d(P, prefix + "xception_features.", x_in, ctx, os)
@@ -195,6 +260,11 @@ def deeplab3d(P: State, prefix: str, x_in: torch.Tensor, ctx: NormCtx, os: int =
     x = torch.cat(branches, dim=1)
     x = q(lrelu(norm(P, prefix + "bn1", q(F.conv3d(x, q(P[prefix + "conv1.weight"]))), ctx)))
     low = q(lrelu(norm(P, prefix + "bn2", q(F.conv3d(low, q(P[prefix + "conv2.weight"]))), ctx)))
+    if prefix + "upsample.deconv1.0.weight" in P:
+        x = deconv_upsampler3d(P, prefix + "upsample.", x, low, ctx)
+        if prefix + "upsample_extension.conv1.0.weight" in P:
+            return upsampler_extension3d(P, prefix + "upsample_extension.", x_in, x, ctx)
+        return F.avg_pool3d(x, 2, 1, 1)
     D, H, W = x_in.shape[2:]
     x = q(trilinear_ac(x, (ceil_div(D, 4), ceil_div(H, 4), ceil_div(W, 4))))
     x = torch.cat((x, low), dim=1)

@@ -437,6 +437,46 @@ def golden_gan3d(c=1, d=16, h=24, w=24, n=2):
     print("gan3d goldens written: g loss", float(res["g::loss"]), "gp", float(res["gp::value"]))
 
 
+def golden_gan3d_deconv(c=2, d=21, h=19, w=21, n=2):
+    """3-D generators with the Deconv (the default of train_gan3d.py:575) and Deconv1x upsamplers (deeplab3d.py:342-444,
+    518-532) on a volume their output paddings fit (D = 4a-3, H = 4b-1, W = 4c-3)."""
+    res, keys = {}, {}
+    x, y = orc3.synthetic_volumes(n, c, d, h, w, 141)
+    for tag, up, seed in (("deconv", "Deconv", 41), ("deconv1x", "Deconv1x", 42)):
+        g = ref_gan3d.Generator(c, c, up, "Uniform", 0, os=16, pretrained=False, normalizer=nn.BatchNorm3d)
+        gspec = orc3.generator3d_spec(c, c, 0, "batch", upsampler=up)
+        _load_checked(g, gspec, seed)
+        g.train()
+        out = g(x)
+        assert out.shape == y.shape, (out.shape, y.shape)
+        loss = (out - y).abs().mean()
+        loss.backward()
+        res[f"{tag}::out"], res[f"{tag}::loss"] = out.detach().numpy(), np.array(loss.item())
+        cs = checksums((k, p.grad) for k, p in g.named_parameters())
+        res[f"{tag}::grad_keys"], res[f"{tag}::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+        named = dict(g.named_parameters())
+        watch = ["model.upsample.conv1.6.bias", "model.upsample.deconv2.1.weight", "model.xception_features.conv1.weight"]
+        if up == "Deconv1x":
+            watch += ["model.upsample_extension.conv1.0.weight", "model.upsample_extension.init_norm.0.bias",
+                      "model.upsample_extension.conv2.3.weight"]
+        else:
+            watch += ["model.upsample.last_deconv.0.weight"]
+        for k in watch:
+            res[f"{tag}::grad::" + k] = named[k].grad.numpy()
+        for k in ("model.upsample.deconv1.0.weight", "model.upsample.deconv3.0.weight"):   # every 8th channel pair
+            res[f"{tag}::grad8::" + k] = named[k].grad[::8, ::8].contiguous().numpy()
+        sd = g.state_dict()
+        for k in ("model.upsample.deconv1.1.running_mean", "model.upsample.deconv3.1.running_var"):
+            res[f"{tag}::buf::" + k] = sd[k].numpy()
+        keys["generator3d_" + tag] = [[k, list(v.shape)] for k, v in sd.items()]
+    np.savez_compressed(os.path.join(HERE, f"gan3d_deconv_c{c}_{d}x{h}x{w}.npz"),
+                        meta=json.dumps(dict(c=c, d=d, h=h, w=w, n=n, seeds={"deconv": 41, "deconv1x": 42}, field_seed=141)),
+                        **res)
+    with open(os.path.join(HERE, "state_dict_keys_3d_deconv.json"), "w") as f:
+        json.dump(keys, f)
+    print("gan3d deconv goldens written:", {t: float(res[t + "::loss"]) for t in ("deconv", "deconv1x")})
+
+
 def golden_infill3d(cin=2, cout=1, d=32, h=24, w=40, n=2, g_layers=4, d_layers=5):
     """Partial-convolution U-Net generator and discriminator in 3-D + the inpainting loss."""
     res = {}
@@ -606,6 +646,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     if "all" in which or "infill3d" in which:
         golden_infill3d()
+    if "all" in which or "gan3d_deconv" in which:
+        golden_gan3d_deconv()
     if "all" in which or "infill2d" in which:
         golden_infill2d()
     if "all" in which or "infill3d_trajectory" in which:

@@ -253,3 +253,90 @@ def test_trainer3d_schedule_and_updates():
         assert (not torch.equal(D.arena().master, d0)) == d_moves, schedule
         # BatchNorm statistics move on every iteration regardless of the schedule (train-mode forwards)
         assert int(D.state_dict()["xception_features.bn1.num_batches_tracked"]) == 6
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("op", [(1, 1, 1), (0, 1, 0), (0, 0, 0)])
+def test_conv_transpose3d(dtype, op):
+    """nn.ConvTranspose3d(3, stride 2, padding 1, output_padding) = the 2-D data-gradient GEMM over the KD*C channel
+    blocks + depth fold (deeplab3d.py:351,356,372,378): forward, input and weight gradients."""
+    n, cin, cout, d, h, w = 2, 24, 16, 3, 5, 4
+    m = d3.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=op, bias=False).set_compute_dtype(dtype)
+    wt = rnd((cin, cout, 3, 3, 3), 51, dtype, 1.0 / np.sqrt(cin * 27 / 8))
+    m.weight.data.copy_(wt)
+    m.to(DEV)
+    x = rnd((n, cin, d, h, w), 52, dtype)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv_transpose3d(xr, wr, None, 2, 1, op)
+    go = rnd(tuple(ref.shape), 53, dtype)
+    ref.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    y = d3.from_folded(m(d3.to_folded(xd, pad_to(cin, vec_of(dtype)), dtype), n), n, cout)
+    assert tuple(y.shape) == tuple(ref.shape)
+    close(y.detach().cpu(), ref.detach(), tol(dtype), "y")
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    close(xd.grad.cpu(), xr.grad, 2 * tol(dtype), "dx")
+    close(m.weight.grad.cpu(), wr.grad, 5e-4 if dtype == F32 else 2e-2, "dw")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("p", [0, 1])
+def test_avgpool3d_2(dtype, p):
+    """nn.AvgPool3d(2, stride=1, padding=p) as depth pair mean of 2 x 2 means (count_include_pad)."""
+    n, c, d, h, w = 2, 16, 4, 5, 6
+    x = rnd((n, c, d, h, w), 54, dtype).requires_grad_(True)
+    ref = F.avg_pool3d(x, 2, 1, p)
+    go = rnd(tuple(ref.shape), 55, dtype)
+    ref.backward(go)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = d3.from_folded(ops.avgpool3d_2(d3.to_folded(xd, pad_to(c, vec_of(dtype)), dtype), n, p), n, c)
+    assert tuple(y.shape) == tuple(ref.shape)
+    close(y.detach().cpu(), ref.detach(), tol(dtype), "y")
+    y.backward(go.to(DEV))
+    close(xd.grad.cpu(), x.grad, tol(dtype), "dx")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("tag,up", [("deconv", "Deconv"), ("deconv1x", "Deconv1x")])
+def test_generator3d_deconv_vs_reference_golden(golden_dir, tag, up, dtype):
+    """3-D Generator with the Deconv (train_gan3d.py's default) and Deconv1x upsamplers against the reference's
+    modules at 21x19x21 (a volume the output paddings fit)."""
+    z = np.load(os.path.join(golden_dir, "gan3d_deconv_c2_21x19x21.npz"))
+    m = json.loads(str(z["meta"]))
+    spec = o3.generator3d_spec(m["c"], m["c"], 0, "batch", upsampler=up)
+    G = g3.Generator(m["c"], m["c"], up, "Uniform", 0, normalizer=nn.BatchNorm3d, compute_dtype=dtype)
+    with open(os.path.join(golden_dir, "state_dict_keys_3d_deconv.json")) as f:
+        assert [[k, list(v.shape)] for k, v in G.state_dict().items()] == json.load(f)["generator3d_" + tag]
+    G.load_state_dict(o3.fill_state(spec, m["seeds"][tag]))
+    G.to(DEV).train()
+    x, y = o3.synthetic_volumes(m["n"], m["c"], m["d"], m["h"], m["w"], m["field_seed"])
+    out = G(x.to(DEV))
+    assert tuple(out.shape) == tuple(z[f"{tag}::out"].shape) and out.dtype == torch.float32
+    ref = torch.from_numpy(z[f"{tag}::out"])
+    r = rms(out.detach().cpu(), ref)
+    print(f"generator3d {up} {dtype}: fwd rms-rel {r:.2e}")
+    if dtype == F32:
+        close(out.detach().cpu(), ref, 2e-4, "out")
+    else:
+        assert r <= 5e-1          # as for the Interpolate generator above (2-sample BatchNorm over 2x2x2 maps)
+    loss = (out - y.to(DEV)).abs().mean()
+    assert abs(loss.item() - float(z[f"{tag}::loss"])) <= (1e-5 if dtype == F32 else 1e-1) * float(z[f"{tag}::loss"])
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(G.named_parameters())
+    worst = 0.0
+    for k in z.files:
+        if k.startswith(f"{tag}::grad::"):
+            worst = max(worst, rms(named[k.split("::", 2)[2]].grad.cpu(), z[k]))
+        if k.startswith(f"{tag}::grad8::"):
+            worst = max(worst, rms(named[k.split("::", 2)[2]].grad[::8, ::8].cpu(), z[k]))
+    print(f"generator3d {up} {dtype}: selected gradients worst rms-rel {worst:.2e}")
+    if dtype == F32:
+        assert worst <= 3e-2
+        sd = G.state_dict()
+        for k in z.files:
+            if k.startswith(f"{tag}::buf::"):
+                close(sd[k.split("::", 2)[2]].cpu(), torch.from_numpy(z[k]), 1e-4, k)
+    else:
+        assert all(torch.isfinite(p.grad).all() for p in G.parameters())
