@@ -25,6 +25,7 @@
 // dtype BG_F32 runs the same kernels on the f32-input MFMA (16x16x4 / 32x32x2):
 // exact fp32 products and accumulation, used as the parity path.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 namespace {
@@ -567,6 +568,78 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
 #endif
 }
 
+
+// ------------------------------------------------ small-Cin data gradient ----
+// Data gradient of the networks' FIRST convolution (3x3, stride 2, pad 1, Cin <= 16 field channels): the implicit
+// GEMM above would spend a 128-row tile on 16 output channels and three of four taps on the stride lattice's
+// holes (38 TFLOP/s).  Here a wave owns 16 output pixels of one row and one column parity -- their contributing
+// (ho, wo) are then consecutive and the taps of the parity class are known (1, 2, 2 or 4 of the 9) -- and the 16
+// input channels are exactly one MFMA 16x16x32 tile: A = W^T[ci][co] from the CRSK copy, B = dy[pixel][co], both
+// K-contiguous 16-byte loads straight into registers (no LDS: nothing is shared between waves).
+struct SmallCDgradParams {
+    const bf16_t* dy; const bf16_t* wt; bf16_t* dx;
+    int N, H, W, Ho, Wo, Co, CKp, ldy, ldx, Ci, tiles_w;
+    long long tiles;
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void dgrad_s2_smallc_kernel(SmallCDgradParams P) {
+    constexpr int NK = CO / 32;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    // the four waves of a block take the four parity classes (row parity, column parity): a wave's tap set is fixed,
+    // so its weight fragments are loaded once and stay in registers
+    const int cls = threadIdx.x >> 6, ph = cls >> 1, pw = cls & 1;
+    const int nr = ph ? 2 : 1, ns = pw ? 2 : 1;
+    const bool a_ok = r16 < P.Ci;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 a[2][2][NK];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = ph ? 2 * i : 1, s_ = pw ? 2 * j : 1;
+            const bf16_t* ap = P.wt + ((long long)(a_ok ? r16 : 0) * 9 + r * 3 + s_) * P.CKp + q * 8;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) a[i][j][k] = (a_ok && i < nr && j < ns) ? *reinterpret_cast<const bf16x8*>(ap + k * 32) : zero8;
+        }
+    const int rows_c = (P.H - ph + 1) / 2;                       // rows of this parity
+    const long long tiles_c = (long long)P.N * rows_c * P.tiles_w;
+    for (long long tile = blockIdx.x; tile < tiles_c; tile += gridDim.x) {
+        long long t = tile;
+        const int tw = (int)(t % P.tiles_w); t /= P.tiles_w;
+        const int h = 2 * (int)(t % rows_c) + ph;
+        const int n = (int)(t / rows_c);
+        const int w = tw * 32 + pw + 2 * r16;       // this lane's output column (B column / stored pixel)
+        bf16x8 b[2][2][NK];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = ph ? 2 * i : 1, s_ = pw ? 2 * j : 1;
+                const int ho = (h + 1 - r) >> 1, wo = (w + 1 - s_) >> 1;
+                const bool ok = i < nr && j < ns && w < P.W && (unsigned)ho < (unsigned)P.Ho && (unsigned)wo < (unsigned)P.Wo;
+                const bf16_t* bp = P.dy + (((long long)n * P.Ho + (ok ? ho : 0)) * P.Wo + (ok ? wo : 0)) * P.ldy + q * 8;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) b[i][j][k] = ok ? *reinterpret_cast<const bf16x8*>(bp + k * 32) : zero8;
+            }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (i < nr && j < ns) {              // wave-uniform
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][j][k], b[i][j][k], acc, 0, 0, 0);
+                }
+            }
+        const int ci = q * 4;
+        if (w < P.W && ci < P.Ci) {
+            bf16x4 o = {(bf16_t)acc[0], (bf16_t)acc[1], (bf16_t)acc[2], (bf16_t)acc[3]};
+            *reinterpret_cast<bf16x4*>(P.dx + (((long long)n * P.H + h) * P.W + w) * P.ldx + ci) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad ----
 struct WgradParams {
     const void* x;
@@ -580,6 +653,9 @@ struct WgradParams {
     long long pix_per_split;  // multiple of 32
     int tiles_co, tiles_ci;
     int x_bytes, dy_bytes;    // exact operand extents (buffer-load range check)
+    int fold;                 // 1: the (tap, ci) pairs are ONE column dimension of RS*Ci (im2col'd x operand) -- the
+                              // few-channel first layers, where a tap per tile would re-read dy nine times for
+                              // 16 useful columns of 128
 };
 
 constexpr int WG_PIX = 32;  // pixels per K-chunk
@@ -659,7 +735,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     // L2); give each XCD a CONTIGUOUS range of the split-major order, so the tiles that re-read
     // one split's pixels (dy for every ci tile, x for every co tile) hit in one L2 instead of
     // being fetched from HBM by all eight.
-    const int tiles = P.tiles_co * P.tiles_ci * RS;
+    const int tiles = P.fold ? P.tiles_co * P.tiles_ci : P.tiles_co * P.tiles_ci * RS;
     int lin = blockIdx.x;
     {
         const int nblk = gridDim.x;
@@ -670,9 +746,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     int bid = lin - split * tiles;
     const int tile_ci = bid % P.tiles_ci;
     bid /= P.tiles_ci;
-    const int tap = bid % RS;
-    const int tile_co = bid / RS;
-    const int r = tap / P.KW, s = tap - r * P.KW;
+    const int tap = P.fold ? 0 : bid % RS;
+    const int tile_co = P.fold ? bid : bid / RS;
     const int co_base = tile_co * TILE, ci_base = tile_ci * TILE;
 
     const long long p_begin = (long long)split * P.pix_per_split;
@@ -683,7 +758,15 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     const int chunk = tid % CPR, row0 = tid / CPR;
     constexpr int ES = (int)sizeof(T);
     const bool co_ok = co_base + chunk * VEC < P.Co;
-    const bool ci_ok = ci_base + chunk * VEC < P.Ci;
+    // this thread's x chunk: channel offset and tap (per block normally; per chunk when the taps are folded in)
+    int cix = ci_base + chunk * VEC, my_tap = tap;
+    bool ci_ok = cix < P.Ci;
+    if (P.fold) {
+        my_tap = cix / P.Ci;
+        cix -= my_tap * P.Ci;
+        ci_ok = my_tap < RS;
+    }
+    const int r = my_tap / P.KW, s = my_tap - r * P.KW;
     const int ohw = P.Ho * P.Wo;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.x), 0, P.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.dy), 0, P.dy_bytes, 0x00020000);
@@ -724,7 +807,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
                 const int ih = r_oh[i] * P.stride - P.pad + r * P.dil;
                 const int iw = r_ow[i] * P.stride - P.pad + s * P.dil;
                 if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
-                    ox = (((r_n[i] * P.H + ih) * P.W + iw) * P.ldx + ci_base + chunk * VEC) * ES;
+                    ox = (((r_n[i] * P.H + ih) * P.W + iw) * P.ldx + cix) * ES;
             }
 #ifdef ABL_W_NO_LOAD
             ox = OOB;
@@ -781,14 +864,18 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ci = ci_base + wave_n * 64 + j * 32 + c32;
-            if (ci >= P.Ci) continue;
+            int ci = ci_base + wave_n * 64 + j * 32 + c32, tap_e = tap;
+            if (P.fold) {
+                tap_e = ci / P.Ci;
+                ci -= tap_e * P.Ci;
+                if (tap_e >= RS) continue;
+            } else if (ci >= P.Ci) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co_base + wave_m * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (co >= P.Co) continue;
 #ifndef ABL_W_NO_ATOMIC
-                atomicAdd(P.dw + ((long long)co * RS + tap) * P.Ci + ci, acc[i][j][e]);
+                atomicAdd(P.dw + ((long long)co * RS + tap_e) * P.Ci + ci, acc[i][j][e]);
 #else
                 if (acc[i][j][e] == 12345.678f) P.dw[0] = 1.f;  // keeps the accumulators alive
 #endif
@@ -990,6 +1077,18 @@ extern "C" int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const v
     if (rc) return rc;
     BG_CHECK_ARG(dy && wt && dx && aligned16(dy) && aligned16(wt) && aligned16(dx),
                  "bg_conv2d_bwd_data: null/unaligned pointer");
+    static const bool smallc = !getenv("BGAMD_NO_SMALLC");
+    if (smallc && d->dtype == BG_BF16 && d->Cin <= 16 && d->Cin % 4 == 0 && d->KH == 3 && d->KW == 3 && d->stride == 2 &&
+        d->pad == 1 && d->dil == 1 && (d->Cout == 128 || d->Cout == 64) && d->ldx % 4 == 0) {
+        SmallCDgradParams Q{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, d->N, d->H, d->W, d->Ho, d->Wo, d->Cout,
+                            pad_k(d->Cout, BG_BF16), d->ldy, d->ldx, d->Cin, (d->W + 31) / 32, 0};
+        Q.tiles = (long long)d->N * ((d->H + 1) / 2) * Q.tiles_w;     // per parity class (the even rows: the larger count)
+        const long long blocks = std::min<long long>(Q.tiles, 256 * 8);
+        if (d->Cout == 128) hipLaunchKernelGGL(dgrad_s2_smallc_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Q);
+        else hipLaunchKernelGGL(dgrad_s2_smallc_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Q);
+        BG_CHECK_LAUNCH("dgrad_s2_smallc_kernel");
+        return BG_OK;
+    }
     GemmConvParams P{};
     P.in = dy; P.w = wt; P.out = dx; P.bias = nullptr;
     P.N = d->N; P.IH = d->Ho; P.IW = d->Wo; P.OH = d->H; P.OW = d->W;
@@ -1014,7 +1113,11 @@ extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const 
     P.M = (long long)d->N * d->Ho * d->Wo;
     P.tiles_co = (d->Cout + TILE - 1) / TILE;
     P.tiles_ci = (d->Cin + TILE - 1) / TILE;
-    const long long tiles = (long long)P.tiles_co * P.tiles_ci * d->KH * d->KW;
+    static const bool fold_ok = !getenv("BGAMD_NO_WGRAD_FOLD");
+    const int vec_w = 16 / (int)dtype_size(d->dtype);
+    P.fold = fold_ok && d->KH * d->KW > 1 && d->Cin <= 32 && d->Cin % vec_w == 0;
+    if (P.fold) P.tiles_ci = (d->KH * d->KW * d->Cin + TILE - 1) / TILE;
+    const long long tiles = P.fold ? (long long)P.tiles_co * P.tiles_ci : (long long)P.tiles_co * P.tiles_ci * d->KH * d->KW;
     // enough pixel splits to put ~1024 workgroups on the chip, each with >= 256 pixels
     // Pixel splits: two 256-thread workgroups fit a CU (VGPRs), so one full wave of the chip
     // is 512 workgroups.  Fill about one wave: more splits only add float-atomic traffic

@@ -95,6 +95,8 @@ CONV_CASES = [
     (1, 16, 16, 304, 256, 3, 1, 1, 1),
     (3, 5, 6, 2048, 256, 3, 1, 2, 2),
     (2, 8, 8, 4, 4, 1, 1, 0, 1),
+    (2, 40, 70, 16, 128, 3, 2, 1, 1),     # first-layer shape class: the small-Cin stride-2 data-gradient kernel (bf16)
+    (1, 37, 35, 12, 64, 3, 2, 1, 1),
 ]
 
 
