@@ -969,7 +969,12 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
         const long long ksteps = (long long)P.KH * P.KW * ((P.CK + 31) / 32);
         wide = ksteps >= 16 && cost256 < 0.98 * cost128;
     }
-    const int tp = wide ? 256 : TILE;
+    // NO <= 128 on very many pixels (the entry flow): 128 x 256 tiles halve the tile count -- these launches are
+    // HBM-bound and their statistics epilogue contends on 2 * NO atomic addresses once per tile
+    static const long long flat_min = getenv("BGAMD_FLAT_MIN") ? atoll(getenv("BGAMD_FLAT_MIN")) : 2048;
+    const bool flat = !tall && dma_mode == 1 && tp_mode != 0 && (P.M + 127) / 128 >= flat_min &&
+                      (P.stat_group_pix == 0 || P.stat_group_pix % 256 == 0);
+    const int tp = (wide || flat) ? 256 : TILE;
     P.tiles_c = (P.NO + tch - 1) / tch;
     P.tiles_p = (int)((P.M + tp - 1) / tp);
     const long long nblk = (long long)P.tiles_c * P.tiles_p;
@@ -997,6 +1002,15 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
             }
             if (nbuf == 3) hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3, 256, 256>), dim3((unsigned)nblk), dim3(1024), sh, st, P);
             else hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 4, 256, 256>), dim3((unsigned)nblk), dim3(1024), sh, st, P);
+        } else if (flat) {
+            const size_t sh = 3 * (TILE + 256) * 64;  // 72 KiB
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, 64, 3, TILE, 256>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                once = true;
+            }
+            hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3, TILE, 256>), dim3((unsigned)nblk), dim3(512), sh, st, P);
         } else if (tall) {
             const size_t sh = 3 * (256 + TILE) * 64;  // 72 KiB
             static bool once = false;
