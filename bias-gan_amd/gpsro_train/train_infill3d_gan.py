@@ -34,10 +34,23 @@ class InfillGANTrainer:
         self.warmup, self.acc_min, self.acc_max = gen_warmup_steps, disc_acc_min, disc_acc_max
         self.g_scheduler, self.d_scheduler = g_scheduler, d_scheduler
         self.step_count = 0
-        self.d_acc_avg = 0.5                       # infill3d_gan_module.py:268
+        self._d_acc = 0.5                          # infill3d_gan_module.py:268
+        self._acc_pending = None                   # (pinned host scalar, event) of the accuracy still in flight
         self.last_flags = (True, True)
         self.last_terms = {}
         self._d_params = [p for p in _unwrap(discriminator).parameters()]
+
+    @property
+    def d_acc_avg(self):
+        """The discriminator accuracy of the last iteration (the reference's `d_acc_avg`).  It is only needed when the
+        NEXT iteration picks its update flags, so its read-back is asynchronous: a copy into pinned memory behind the
+        D part, waited for here -- the host keeps enqueueing the G part instead of stalling in the middle of a step."""
+        if self._acc_pending is not None:
+            host, ev, scale = self._acc_pending
+            ev.synchronize()
+            self._d_acc = float(host) * scale
+            self._acc_pending = None
+        return self._d_acc
 
     def update_flags(self):
         """(train_generator, train_discriminator), infill3d_gan_module.py:294-311."""
@@ -65,8 +78,19 @@ class InfillGANTrainer:
             d_loss = self.criterion_gan.d_loss(logits_real, logits_fake, labels) * self.loss_weights["adv"]
         with torch.no_grad():   # utils/metrics.py:18-32 against labels 1 / 0: sigmoid(logit) > 0.5  <=>  logit > 0
             acc = 0.5 * ((logits_real > 0).float().mean() + (logits_fake <= 0).float().mean())
-        # the accuracy steers the NEXT iteration: a host value, as the reference's metric_average returns one
-        self.d_acc_avg = comm.metric_average(acc, "train_accuracy_d", device=acc.device) if comm is not None else float(acc)
+        # the accuracy steers the NEXT iteration (a host value in the reference: metric_average's SUM over ranks)
+        if comm is not None and comm.size() > 1:
+            import torch.distributed as dist
+            acc = acc.clone()
+            dist.all_reduce(acc)
+        if acc.is_cuda:
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host.copy_(acc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._acc_pending = (host, ev, 1.0)
+        else:
+            self._d_acc = float(acc)
         if train_d:
             self.d_opt.zero_grad()
             d_loss.backward()

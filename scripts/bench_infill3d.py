@@ -13,7 +13,7 @@ from bias_gan_amd.utils import losses, parsing_helpers as ph
 
 dev = torch.device("cuda", 0)
 W = {"valid": 1.0, "hole": 0.5, "tv": 0.1, "adv": 0.5}
-for (n, d, h, w) in ((4, 45, 19, 37), (16, 45, 19, 37), (4, 64, 96, 96)):
+for (n, d, h, w) in ((4, 45, 19, 37), (16, 45, 19, 37), (4, 64, 96, 96), (4, 45, 19, 37)):
     with contextlib.redirect_stdout(io.StringIO()):
         net = ig.GAN(input_channels=2, output_channels=1, gen_layer_size=6, disc_layer_size=6)
         G, D = net.generator.set_compute_dtype(torch.bfloat16).to(dev), net.discriminator.set_compute_dtype(torch.bfloat16).to(dev)
