@@ -80,6 +80,9 @@ _SIGS = {
     "bg_dwconv3x3x3_bwd_weight": [C.POINTER(Dw3Desc), c_vp, c_vp, c_vp, c_vp],
     "bg_depth_resize_fwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_depth_resize_bwd": [c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_conv2d_fwd_splitk": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp],
+    "bg_conv2d_bwd_data_splitk": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_i32, c_vp],
+    "bg_splitk_reduce": [c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp],
     "bg_depth_avg2": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_mask_window": [c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],

@@ -52,6 +52,8 @@ struct GemmConvParams {
     int CKp;       // K stride of one tap inside the (zero-padded) weight copy
     int in_bytes;  // exact extent of the activation operand (buffer-load range check)
     int w_bytes;
+    float* ws;         // split-K: fp32 [splits][M][NO]; every split stores its partial tile into its own slice
+    int kt_per_split;  // split-K: K-steps per split
 };
 
 template <int BKB>
@@ -390,7 +392,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // The kernel is bound by operand delivery into LDS, not by the MFMAs (an ablation build without the
 // MFMAs runs as fast, one without the loads 1.5-1.8x faster); 256 x 128 moves 25 % fewer operand bytes
 // per FLOP than 128 x 128 and puts 16 waves on a CU (2 workgroups x 72 KiB of LDS).
-template <typename T, int BKB, int NBUF, int TCH, int TP = TILE>
+template <typename T, int BKB, int NBUF, int TCH, int TP = TILE, bool SPLIT = false>
 __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvParams P) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BK = BKB / ES;
@@ -419,6 +421,12 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
     {
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    int split = 0;
+    if (SPLIT) {   // split-K: the grid is (tiles x splits); a block owns K-steps [split * kt_per_split, ...)
+        const int ntile = P.tiles_c * P.tiles_p;
+        split = bid / ntile;
+        bid -= split * ntile;
     }
     const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
     const long long p_base = (long long)tile_p * TP;
@@ -467,12 +475,23 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
 #ifdef ABL_KT1   // ablation: one K-step only -> what a tile costs besides its K loop
     const int KT = 1;
 #else
-    const int KT = RS * ksteps_per_tap;
+    int KT = RS * ksteps_per_tap;
 #endif
 #pragma unroll
     for (int g = 0; g < NGB; ++g) tail_cut[g] = (ksteps_per_tap - 1) * BK + chk16[g] / ES >= P.CK;
 
     int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
+    bool fresh = SPLIT;   // split-K: the first issue starts in the middle of a tap
+    if (SPLIT) {
+#ifndef ABL_KT1
+        const int kt0 = split * P.kt_per_split;
+        KT = min(P.kt_per_split, KT - kt0);   // >= 1 (launcher)
+        l_tap = kt0 / ksteps_per_tap;
+        l_ks = kt0 - l_tap * ksteps_per_tap;
+        l_tap_r = l_tap / P.KW;
+        l_tap_s = l_tap - l_tap_r * P.KW;
+#endif
+    }
     int va[NGA], vb[NGB];
     auto start_tap = [&]() {
         const int dh = sgn * l_tap_r * P.dil, dw_ = sgn * l_tap_s * P.dil;
@@ -496,6 +515,14 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
     };
     auto issue = [&](int buf) {
         if (l_ks == 0) start_tap();
+        else if (SPLIT && fresh) {
+            start_tap();
+#pragma unroll
+            for (int g = 0; g < NGA; ++g) va[g] += l_ks * BKB;   // an out-of-range marker stays out of range
+#pragma unroll
+            for (int g = 0; g < NGB; ++g) vb[g] += l_ks * BKB;
+        }
+        fresh = false;
         char* stage_a = smem + buf * STAGE_BYTES + wave * ROWS_A * BKB;
         char* stage_b = smem + buf * STAGE_BYTES + TILE_BYTES + wave * ROWS_B * BKB;
         const bool last = l_ks == ksteps_per_tap - 1;
@@ -564,10 +591,47 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
         for (int j = 0; j < 4; ++j) chk += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (chk == 1.2345e-33f) reinterpret_cast<float*>(P.out)[0] = chk;
 #else
-    conv_epilogue<T, TCH, TP>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
+    if (SPLIT) {   // partial sums of this K range -> this split's slice of the workspace (plain stores: the sum over
+                   // splits is taken in a fixed order by splitk_reduce_kernel, so results do not depend on scheduling)
+        const int r16 = lane & 15, q = lane >> 4;
+        float* slice = P.ws + (long long)split * P.M * P.NO;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long p = p_base + wave_p * 64 + j * 16 + r16;
+            if (p >= P.M) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = c_base + wave_c * 64 + i * 16 + q * 4;
+                if (co >= P.NO) continue;
+                *reinterpret_cast<f32x4*>(slice + p * P.NO + co) = acc[i][j];
+            }
+        }
+    } else {
+        conv_epilogue<T, TCH, TP>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
+    }
 #endif
 }
 
+
+// y[r][c] = T(sum_s ws[s][r][c]), splits summed in index order (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, long long rows, int C, T* y, int ldy) {
+    const int c4 = C / 4;
+    const long long total = rows * c4, slice = rows * (long long)C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        const float* p = ws + r * C + c;
+        f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        for (int s_ = 1; s_ < splits; ++s_) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p + s_ * slice);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        T* o = y + r * ldy + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f(a[e]);
+    }
+}
 
 // ------------------------------------------------ small-Cin data gradient ----
 // Data gradient of the networks' FIRST convolution (3x3, stride 2, pad 1, Cin <= 16 field channels): the implicit
@@ -936,7 +1000,7 @@ int check_conv_desc(const bg_conv_desc* d, const char* who) {
 }
 
 template <typename T>
-int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
+int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
     GemmConvParams P = P0;
     const int dt = sizeof(T) == 2 ? BG_BF16 : BG_F32;
     P.CKp = pad_k(P.CK, dt);
@@ -948,6 +1012,24 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st) {
     }
     P.in_bytes = (int)in_bytes;
     P.w_bytes = (int)w_bytes;
+    if (splits > 1) {   // split-K (few tiles, long reduction): 128 x 128 tiles, (tiles x splits) blocks, one workspace slice each
+        const int kt_all = P.KH * P.KW * ((P.CK + 64 / (int)sizeof(T) - 1) / (64 / (int)sizeof(T)));
+        P.kt_per_split = (kt_all + splits - 1) / splits;
+        if ((kt_all + P.kt_per_split - 1) / P.kt_per_split != splits) {   // every split must own >= 1 K-step (its slice is read)
+            bg_set_error("conv split-K: %d splits do not divide the %d K-steps into non-empty ranges", splits, kt_all);
+            return BG_E_ARG;
+        }
+        P.tiles_c = (P.NO + TILE - 1) / TILE;
+        P.tiles_p = (int)((P.M + TILE - 1) / TILE);
+        const long long nb = (long long)P.tiles_c * P.tiles_p * splits;
+        if (nb > 0x7fffffffLL) {
+            bg_set_error("conv: grid too large");
+            return BG_E_ARG;
+        }
+        hipLaunchKernelGGL((gemm_conv_dma_kernel<T, 64, 3, TILE, TILE, true>), dim3((unsigned)nb), dim3(NTHREADS), 3 * 2 * TILE * 64, st, P);
+        BG_CHECK_LAUNCH("gemm_conv_dma_kernel(split-K)");
+        return BG_OK;
+    }
     static const int dma_mode = getenv("BGAMD_DMA") ? atoi(getenv("BGAMD_DMA")) : 1;  // 0: register staging; 1: 3-stage ring, 64-byte rows (default); 2: 128-byte rows where they pad less; 3: 4-stage ring
     static const int tch_max = getenv("BGAMD_TCH") ? atoi(getenv("BGAMD_TCH")) : 256;  // A/B switch: 128 = old tile
     // 256 out-channel rows per tile wherever that does not add padding (NO <= 128 stays on 128 x 128)
@@ -1062,6 +1144,50 @@ extern "C" int bg_conv2d_fwd(const bg_conv_desc* d, const void* x, const void* w
     P.M = (long long)d->N * d->Ho * d->Wo;
     if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream);
     return launch_gemm_conv<float>(P, (hipStream_t)stream);
+}
+
+extern "C" int bg_conv2d_fwd_splitk(const bg_conv_desc* d, const void* x, const void* w, float* ws, int32_t splits,
+                                    void* stream) {
+    int rc = check_conv_desc(d, "bg_conv2d_fwd_splitk");
+    if (rc) return rc;
+    BG_CHECK_ARG(x && w && ws && aligned16(x) && aligned16(w) && splits >= 2, "bg_conv2d_fwd_splitk: bad args");
+    GemmConvParams P{};
+    P.in = x; P.w = w; P.out = nullptr; P.bias = nullptr; P.ws = ws;
+    P.N = d->N; P.IH = d->H; P.IW = d->W; P.OH = d->Ho; P.OW = d->Wo;
+    P.CK = d->Cin; P.NO = d->Cout; P.ldi = d->ldx; P.ldo = d->ldy;
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
+    P.transposed = 0;
+    P.M = (long long)d->N * d->Ho * d->Wo;
+    if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream, splits);
+    return launch_gemm_conv<float>(P, (hipStream_t)stream, splits);
+}
+
+extern "C" int bg_conv2d_bwd_data_splitk(const bg_conv_desc* d, const void* dy, const void* wt, float* ws, int32_t splits,
+                                         void* stream) {
+    int rc = check_conv_desc(d, "bg_conv2d_bwd_data_splitk");
+    if (rc) return rc;
+    BG_CHECK_ARG(dy && wt && ws && aligned16(dy) && aligned16(wt) && splits >= 2, "bg_conv2d_bwd_data_splitk: bad args");
+    GemmConvParams P{};
+    P.in = dy; P.w = wt; P.out = nullptr; P.bias = nullptr; P.ws = ws;
+    P.N = d->N; P.IH = d->Ho; P.IW = d->Wo; P.OH = d->H; P.OW = d->W;
+    P.CK = d->Cout; P.NO = d->Cin; P.ldi = d->ldy; P.ldo = d->ldx;
+    P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
+    P.transposed = 1;
+    P.M = (long long)d->N * d->H * d->W;
+    if (d->dtype == BG_BF16) return launch_gemm_conv<bf16_t>(P, (hipStream_t)stream, splits);
+    return launch_gemm_conv<float>(P, (hipStream_t)stream, splits);
+}
+
+extern "C" int bg_splitk_reduce(int32_t dtype, const float* ws, int32_t splits, int64_t rows, int32_t C, void* y, int32_t ldy,
+                               void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && ws && y && splits >= 1 && rows > 0 && C > 0 && C % 4 == 0 && ldy >= C && aligned16(ws),
+                 "bg_splitk_reduce: bad args");
+    long long g = (rows * (C / 4) + 255) / 256;
+    if (g > 65535) g = 65535;
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ws,
+                                                   splits, (long long)rows, C, (T*)y, ldy));
+    BG_CHECK_LAUNCH("splitk_reduce_kernel");
+    return BG_OK;
 }
 
 extern "C" int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, void* y, double* sum,

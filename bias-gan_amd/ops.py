@@ -184,6 +184,32 @@ class FromInternal(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------- convolution
+_SPLITK = not _os.environ.get("BGAMD_NO_SPLITK")
+
+
+def splitk_plan(m_out, n_out, cin, kh, kw, dtype):
+    """Split count for a GEMM launch with few output tiles and a long reduction (0: run it as one launch).  Units as the
+    library's: 128 x 128 tiles, K-steps of 64 bytes of channels per tap.  The count divides the K-steps into non-empty
+    ranges of ceil(K-steps / splits), as the entry points require."""
+    if not _SPLITK:
+        return 0
+    tiles = -(-m_out // 128) * -(-n_out // 128)
+    ksteps = kh * kw * -(-cin // (32 if dtype == torch.bfloat16 else 16))
+    if tiles > 48 or ksteps < 48:
+        return 0
+    splits = min(ksteps // 12, 768 // tiles)
+    if splits < 4:
+        return 0
+    per = -(-ksteps // splits)
+    return -(-ksteps // per)
+
+
+def _splitk_finish(ws, y):
+    """fp32 [splits, rows, C] partial tiles -> the activation tensor: slices summed in index order, rounded to its dtype."""
+    splits, rows, c = ws.shape
+    L.call("bg_splitk_reduce", L.dt(y.dtype), ws.data_ptr(), splits, rows, c, y.data_ptr(), ld_of(y))
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d(groups=1) as implicit GEMM (bg_conv2d_*)."""
 
@@ -200,7 +226,15 @@ class Conv2dFn(torch.autograd.Function):
         wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
-        if stats is not None:
+        splits = splitk_plan(n * ho * wo, kp, cin, kh, kw, x.dtype) if bslot is None else 0
+        if splits:
+            ws = torch.empty((splits, n * ho * wo, kp), dtype=torch.float32, device=x.device)
+            L.call("bg_conv2d_fwd_splitk", desc, x.data_ptr(), arena.weight_ptr(wslot), ws.data_ptr(), splits)
+            _splitk_finish(ws, y)
+            if stats is not None:   # statistics of the values as stored, like the fused epilogue
+                L.call("bg_norm_stats", L.dt(y.dtype), y.data_ptr(), n * ho * wo, kp, ld_of(y), stats.shape[1],
+                       stats[0].data_ptr(), stats[1].data_ptr())
+        elif stats is not None:
             # stats: fp64 [2, groups, kp]; groups = sub-batches with separate BatchNorm statistics
             assert bslot is None and stats.dim() == 3 and stats.shape[0] == 2 and stats.shape[2] == kp
             assert stats.dtype == torch.float64
@@ -226,7 +260,13 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = new_act(n, h, w, cin, xdtype, xdev)
             d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(dx), ld_of(g))
-            L.call("bg_conv2d_bwd_data", d2, g.data_ptr(), arena.weight_t_ptr(wslot), dx.data_ptr())
+            splits = splitk_plan(n * h * w, cin, kp, kh, kw, xdtype)
+            if splits:
+                ws = torch.empty((splits, n * h * w, cin), dtype=torch.float32, device=xdev)
+                L.call("bg_conv2d_bwd_data_splitk", d2, g.data_ptr(), arena.weight_t_ptr(wslot), ws.data_ptr(), splits)
+                _splitk_finish(ws, dx)
+            else:
+                L.call("bg_conv2d_bwd_data", d2, g.data_ptr(), arena.weight_t_ptr(wslot), dx.data_ptr())
         if ctx.needs_input_grad[1]:
             (x,) = ctx.saved_tensors
             desc = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(g))

@@ -86,6 +86,16 @@ int bg_conv2d_fwd_stats(const bg_conv_desc* d, const void* x, const void* w, voi
 int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const void* wt, void* dx, void* stream);
 /* dw += x (*) dy, dw fp32 KRSC (accumulated with float atomics; caller zeroes it
  * once per backward pass).  dbias (fp32 [Cout], may be NULL) += sum over pixels of dy. */
+/* Split-K forms for launches with few output tiles and a long reduction (3x3x3 convolutions on the 1x2x3 maps at the
+ * bottom of the 3-D nets: one or two 128 x 128 tiles walking > 1000 K-steps): (tiles x splits) workgroups, each
+ * stores its K range's partial tile into its own slice of ws, fp32 [splits][N*Ho*Wo][Cout] (resp.
+ * [splits][N*H*W][Cin]); bg_splitk_reduce then sums the slices in index order -- no atomics, results independent of
+ * scheduling -- and rounds to the activation dtype; for a BatchNorm that follows the caller takes bg_norm_stats of
+ * the result.  `splits` must divide the K-steps (KH*KW*ceil(C/32) for bf16, /16 for fp32) into non-empty ranges
+ * of ceil(K-steps / splits).  No bias. */
+int bg_conv2d_fwd_splitk(const bg_conv_desc* d, const void* x, const void* w, float* ws, int32_t splits, void* stream);
+int bg_conv2d_bwd_data_splitk(const bg_conv_desc* d, const void* dy, const void* wt, float* ws, int32_t splits, void* stream);
+int bg_splitk_reduce(int32_t dtype, const float* ws, int32_t splits, int64_t rows, int32_t C, void* y, int32_t ldy, void* stream);
 int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* stream);
 
 /* Reduction-dimension padding granule of the packed weight copies (elements). */

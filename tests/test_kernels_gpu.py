@@ -763,3 +763,54 @@ def test_pixel_losses(kind, weighted):
     got.backward()
     assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
     assert_close(pd.grad.cpu(), p.grad, 1e-5, "dp")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 3, 4, 512, 264, 3, 1, 1, 1), (4, 1, 1, 2048, 256, 1, 1, 0, 1), (1, 5, 6, 96, 40, 3, 2, 1, 1),
+                                  (2, 4, 3, 1032, 136, 3, 1, 2, 2)])
+def test_conv_split_k(case, dtype):
+    """bg_conv2d_fwd_splitk / bg_conv2d_bwd_data_splitk + bg_splitk_reduce (few tiles, long reduction): partial tiles
+    of K ranges in per-split workspace slices, summed in index order == the one-launch convolution, bit-identical
+    from run to run; a split starting in the middle of a tap, strided and dilated taps."""
+    n, h, w, cin, cout, k, s, p, d = case
+    x = rnd((n, cin, h, w), 61, dtype)
+    wt = rnd((cout, cin, k, k), 62, dtype, 1.0 / math.sqrt(cin * k * k))
+    cinp, coutp = up(cin, dtype), up(cout, dtype)
+    desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, k, s, p, d, cinp, coutp)
+    xb, xv = to_nhwc(x, dtype)
+    wpk, wpt = pack(krsc(wt, dtype), dtype)
+    ref = F.conv2d(x, wt, None, s, p, d)
+    gran = 32 if dtype == torch.bfloat16 else 16
+
+    def legal(ksteps, want):       # the split counts the entry points accept: non-empty ranges of ceil(ksteps / splits)
+        per = -(-ksteps // want)
+        return -(-ksteps // per)
+
+    kf, kb = k * k * -(-cinp // gran), k * k * -(-coutp // gran)
+    for want in (2, 5, 7):
+        splits = legal(kf, want)
+        outs = []
+        for _ in range(2):
+            ws = torch.full((splits, n * ho * wo, coutp), float("nan"), device=DEV)
+            yb = torch.zeros(n, ho, wo, coutp + 8, dtype=dtype, device=DEV)
+            L.call("bg_conv2d_fwd_splitk", desc, xv.data_ptr(), wpk.data_ptr(), ws.data_ptr(), splits)
+            L.call("bg_splitk_reduce", L.dt(dtype), ws.data_ptr(), splits, n * ho * wo, coutp, yb.data_ptr(), coutp + 8)
+            outs.append(yb)
+        assert torch.equal(outs[0], outs[1])
+        assert_close(from_nhwc(outs[0][..., :coutp], cout), ref, tol(dtype), f"fwd, {splits} splits")
+        assert (outs[0][..., cout:] == 0).all()
+    go = rnd((n, cout, ho, wo), 63, dtype)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, wt, None, s, p, d).backward(go)
+    gb, gv = to_nhwc(go, dtype)
+    for want in (3, 6):
+        splits = legal(kb, want)
+        ws = torch.full((splits, n * h * w, cinp), float("nan"), device=DEV)
+        dxb = torch.zeros(n, h, w, cinp, dtype=dtype, device=DEV)
+        L.call("bg_conv2d_bwd_data_splitk", desc, gv.data_ptr(), wpt.data_ptr(), ws.data_ptr(), splits)
+        L.call("bg_splitk_reduce", L.dt(dtype), ws.data_ptr(), splits, n * h * w, cinp, dxb.data_ptr(), cinp)
+        assert_close(from_nhwc(dxb, cin), xr.grad, tol(dtype), f"bwd_data, {splits} splits")
+    bad = next((c_ for c_ in range(2, kf) if legal(kf, c_) != c_), None)   # a count that would leave a split empty
+    if bad is not None:
+        with pytest.raises(RuntimeError, match="non-empty"):
+            L.call("bg_conv2d_fwd_splitk", desc, xv.data_ptr(), wpk.data_ptr(), ws.data_ptr(), bad)
