@@ -15,6 +15,7 @@ import torch
 from ..architecture.gpsro import deeplab_gan as dxg
 from ..comm.distributed import DistributedModel
 from .. import ops
+from ..graphs import NoGradGraph
 from ..runtime import StatsPool
 
 
@@ -56,18 +57,18 @@ class GANTrainer:
         self._g_ahead = None
         self._want_g_ahead = False
         self._d_params = [p for p in _unwrap(discriminator).parameters()]
+        self._g_nograd = NoGradGraph(generator)  # the D-step's generator forward: hipGraph replay where the host is the limiter
 
     # -- train_gan.py:250-271 -------------------------------------------------------------
     def d_step(self, inputs, outputs_real, labels=None, eta=None):
         if not self._train_d:                       # losses / accuracy only: no graph
+            outputs_fake = self._g_nograd(inputs)
             with torch.no_grad():
-                outputs_fake = self.generator(inputs)
                 logits_real, _ = self.discriminator(outputs_real)
                 logits_fake, _ = self.discriminator(outputs_fake)
             return self._d_update(logits_real, logits_fake, outputs_fake, outputs_real, labels, eta)
         if self._batched_d and inputs.is_cuda:
-            with torch.no_grad():                   # no graph through G: D's update cannot use it
-                outputs_fake = self.generator(inputs)
+            outputs_fake = self._g_nograd(inputs)   # no autograd graph through G: D's update cannot use it
             n = outputs_real.shape[0]
             if self._want_g_ahead:
                 if self._side == "auto":
@@ -90,8 +91,7 @@ class GANTrainer:
             main.wait_stream(self._side)
             outputs_fake.record_stream(main)
         else:
-            with torch.no_grad():                   # no graph through G: D's update cannot use it
-                outputs_fake = self.generator(inputs)
+            outputs_fake = self._g_nograd(inputs)   # no autograd graph through G: D's update cannot use it
             logits_real, _ = self.discriminator(outputs_real)
         logits_fake, _ = self.discriminator(outputs_fake)
         return self._d_update(logits_real, logits_fake, outputs_fake, outputs_real, labels, eta)

@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 
 from ..comm.distributed import DistributedModel
+from ..graphs import NoGradGraph
 from ..runtime import StatsPool
 
 
@@ -39,6 +40,7 @@ class InfillGANTrainer:
         self.last_flags = (True, True)
         self.last_terms = {}
         self._d_params = [p for p in _unwrap(discriminator).parameters()]
+        self._g_nograd = NoGradGraph(generator)   # hipGraph replay of the D part's generator forward (graphs.py)
 
     @property
     def d_acc_avg(self):
@@ -70,8 +72,7 @@ class InfillGANTrainer:
         masks = torch.cat((masks_raw, torch.ones_like(noise)), dim=1)
         train_g, train_d = self.last_flags = self.update_flags()
         # ---- discriminator part (:314-341)
-        with torch.no_grad():
-            outputs_fake, _ = self.generator(inputs, masks)
+        outputs_fake, _ = self._g_nograd(inputs, masks)
         with torch.set_grad_enabled(train_d):
             logits_real, _ = self.discriminator(outputs_real, masks)
             logits_fake, _ = self.discriminator(outputs_fake, masks)
