@@ -61,6 +61,7 @@ class NoGradGraph:
             arena.sync()                                # outside the graph: see the module docstring
         if e is None:
             e = self.entries[key] = self._capture(args)
+            e["arena"] = arena      # the key holds id(arena): keeping the arena alive keeps that id from being reused
             return e["out"]
         pool = StatsPool.get(args[0].device)
         if pool.used != e["pool_before"]:               # someone took statistic slots earlier in this step: stay correct
