@@ -54,3 +54,124 @@ class GANTrainer3d(GANTrainer):
         self._finish_d()
         self.step_count += 1
         return d_loss, g_loss
+
+
+def main(pargs):
+    """Command line of the reference's train_gan3d.py (:90-360) on the 3-D HIP path: one-channel volumes whose depth
+    axis is the selected level range (`inputs.unsqueeze(1)`, :267-268), BatchNorm3d generator, InstanceNorm3d critic
+    under the Wasserstein loss (:140), the static / adaptive relative update schedule."""
+    import datetime as dt
+    import os
+
+    import torch
+    import torch.nn as nn
+    from torch.utils.data import DataLoader
+
+    from ..architecture.gpsro import deeplab as dxc
+    from ..comm.distributed import comm as distcomm
+    from ..data import gpsro_dataset as gpsro
+    from ..utils import losses
+    from ..utils import parsing_helpers as ph
+
+    comm = distcomm(mode="dummy" if "RANK" not in os.environ else "torchrun")
+    seed = 333 + 7 * comm.rank()
+    torch.manual_seed(seed)
+    device = torch.device("cuda", comm.local_rank())
+    torch.cuda.set_device(device)
+    if pargs.synthetic_size is not None:
+        d, h, w = pargs.synthetic_size
+        g = torch.Generator(device=device).manual_seed(seed)
+
+        def batches():
+            while True:
+                x = torch.randn((pargs.local_batch_size, d, h, w), generator=g, device=device)
+                m = (torch.rand(x.shape, generator=g, device=device) > 0.1).float() if pargs.enable_masks else None
+                yield x, x + 0.1 * torch.randn(x.shape, generator=g, device=device), m, None
+        train_loader = batches()
+    else:
+        root = pargs.data_dir_prefix
+        train_set = gpsro.GPSRODataset(os.path.join(root, "train"), statsfile=os.path.join(root, "stats3d.npz"),
+                                       channels=pargs.channels,
+                                       normalization_type="MinMax" if pargs.noise_type == "Uniform" else "MeanVariance",
+                                       shuffle=True, masks=pargs.enable_masks, shard_idx=comm.rank(), shard_num=comm.size(),
+                                       num_intra_threads=pargs.max_intra_threads, read_device=device, send_device=device)
+        train_loader = DataLoader(train_set, pargs.local_batch_size, drop_last=True)
+
+    cdt = torch.float32 if pargs.amp_opt_level == "O0" else torch.bfloat16
+    g_norm = dxc.Identity if pargs.disable_batchnorm else nn.BatchNorm3d
+    d_norm = dxc.Identity if pargs.disable_batchnorm else \
+        (nn.InstanceNorm3d if pargs.loss_type_gan == "Wasserstein" else nn.BatchNorm3d)
+    generator = dxg3.Generator(1, 1, pargs.upsampler_type, pargs.noise_type, pargs.noise_dimensions, os=16, pretrained=False,
+                               normalizer=g_norm, compute_dtype=cdt).to(device)
+    discriminator = dxg3.Discriminator(n_input=1, os=16, pretrained=False, normalizer=d_norm, compute_dtype=cdt).to(device)
+    criterion_gan = losses.GANLoss(pargs.loss_type_gan, pargs.local_batch_size, device)
+    if pargs.loss_type_regression == "l1":
+        criterion_regression = losses.L1LossWeighted() if pargs.enable_masks else losses.L1Loss()
+    elif pargs.loss_type_regression == "smooth_l1":
+        criterion_regression = losses.SmoothL1Loss()
+    elif pargs.loss_type_regression == "l2":
+        criterion_regression = losses.MSELoss()
+    else:
+        raise NotImplementedError("Error, loss {} not implemented.".format(pargs.loss_type_regression))
+    g_opt = ph.get_optimizer(generator.parameters(), pargs.optimizer_generator, pargs.start_lr_generator, pargs.adam_eps,
+                             pargs.weight_decay)
+    d_opt = ph.get_optimizer(discriminator.parameters(), pargs.optimizer_discriminator, pargs.start_lr_discriminator,
+                             pargs.adam_eps, pargs.weight_decay)
+    generator.train(), discriminator.train()
+    g_sched = ph.get_lr_schedule(pargs.start_lr_generator, pargs.lr_schedule_generator, g_opt) \
+        if pargs.lr_schedule_generator else None
+    d_sched = ph.get_lr_schedule(pargs.start_lr_discriminator, pargs.lr_schedule_discriminator, d_opt) \
+        if pargs.lr_schedule_discriminator else None
+    trainer = GANTrainer3d(comm.DistributedModel(generator), comm.DistributedModel(discriminator), g_opt, d_opt, criterion_gan,
+                           criterion_regression, loss_type_gan=pargs.loss_type_gan, loss_weight_gan=pargs.loss_weight_gan,
+                           loss_weight_regression=pargs.loss_weight_regression, loss_weight_gp=pargs.loss_weight_gp,
+                           enable_masks=pargs.enable_masks, generator_warmup_steps=pargs.generator_warmup_steps,
+                           g_scheduler=g_sched, d_scheduler=d_sched,
+                           relative_update_schedule=pargs.relative_update_schedule or None)
+    if pargs.checkpoint:
+        trainer.load_checkpoint(pargs.checkpoint, comm, device)
+    comm.printr('{:14.4f} REPORT: starting training'.format(dt.datetime.now().timestamp()), 0)
+    epoch, d_avg, g_avg = 0, 0., 0.
+    while trainer.step_count < pargs.max_steps:
+        for batch in train_loader:
+            inputs, outputs_real = batch[0].unsqueeze(1), batch[1].unsqueeze(1)
+            masks = batch[2].unsqueeze(1) if pargs.enable_masks else None
+            d_loss, g_loss = trainer.step(inputs, outputs_real, masks, comm=comm)
+            if trainer.step_count % pargs.logging_frequency == 0 or trainer.step_count == pargs.max_steps:
+                d_avg = comm.metric_average(d_loss, "train_loss_discriminator", device=device)
+                g_avg = comm.metric_average(g_loss, "train_loss_generator", device=device)
+                comm.printr('{:14.4f} REPORT training: step {} d_loss {} g_loss {} d_acc {}'.format(
+                    dt.datetime.now().timestamp(), trainer.step_count, d_avg, g_avg, trainer.d_acc_avg), 0)
+            if pargs.save_frequency > 0 and trainer.step_count % pargs.save_frequency == 0 and comm.rank() == 0:
+                trainer.save_checkpoint(os.path.join(pargs.output_dir, "gan3d_step_{}.cpt".format(trainer.step_count)), epoch)
+            if trainer.step_count >= pargs.max_steps:
+                break
+        epoch += 1
+    return trainer
+
+
+def build_parser():
+    from .train_gan import build_parser as base
+    import argparse as ap
+
+    class StoreDictKeyPair(ap.Action):
+        def __call__(self, parser, namespace, values, option_string=None):
+            setattr(namespace, self.dest, dict(kv.split("=") for kv in values.split(",")))
+
+    AP = base()
+    for a in list(AP._actions):                       # the 3-D script's differences from train_gan.py (:575,592,596)
+        if a.dest in ("synthetic_size", "update_frequency_generator", "update_frequency_discriminator"):
+            AP._remove_action(a)
+            for s in a.option_strings:
+                AP._option_string_actions.pop(s, None)
+    AP.set_defaults(upsampler_type="Deconv", amp_opt_level="O0")
+    AP.add_argument("--relative_update_schedule", action=StoreDictKeyPair, default={},
+                    help="type=static,update_frequency_generator=1,update_frequency_discriminator=1 | "
+                         "type=adaptive,acc_min=0.2,acc_max=0.8")
+    AP.add_argument("--synthetic_size", type=int, nargs=3, default=None, metavar=("D", "H", "W"),
+                    help="train on synthetic N(0,1) volumes of this size instead of a dataset")
+    return AP
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

@@ -340,3 +340,19 @@ def test_generator3d_deconv_vs_reference_golden(golden_dir, tag, up, dtype):
                 close(sd[k.split("::", 2)[2]].cpu(), torch.from_numpy(z[k]), 1e-4, k)
     else:
         assert all(torch.isfinite(p.grad).all() for p in G.parameters())
+
+
+def test_train_gan3d_command_line():
+    """`python -m bias_gan_amd.gpsro_train.train_gan3d` with the reference's flags (train_gan3d.py:560-601) on synthetic
+    volumes: the default Deconv upsampler with the adaptive schedule, and the Wasserstein critic (InstanceNorm3d) with
+    masks, noise channel and bf16."""
+    from bias_gan_amd.gpsro_train import train_gan3d as t3
+    tr = t3.main(t3.build_parser().parse_args(
+        "--synthetic_size 21 19 21 --local_batch_size 2 --max_steps 3 --noise_dimensions 0 "
+        "--relative_update_schedule type=adaptive,acc_min=0.2,acc_max=0.8".split()))
+    assert tr.step_count == 3 and tr.schedule["type"] == "adaptive" and 0.0 <= tr.d_acc_avg <= 1.0
+    tr = t3.main(t3.build_parser().parse_args(
+        "--synthetic_size 16 24 24 --upsampler_type Interpolate --amp_opt_level O1 --enable_masks --loss_type_gan Wasserstein "
+        "--local_batch_size 2 --max_steps 2 --noise_dimensions 1".split()))
+    assert tr.step_count == 2
+    assert all(torch.isfinite(p).all() for p in tr.generator.parameters())
