@@ -127,3 +127,135 @@ class InfillGANTrainer:
         self.last_terms = {k: v.detach() for k, v in terms.items()}
         self.step_count += 1
         return d_loss.detach(), g_loss.detach()
+
+
+class Infill3dGAN:
+    """The reference's training module (gpsro_train/infill3d_gan_module.py:40-245): built from a config dict with the
+    keys of gpsro_configs/infill3d_gan_1.yaml, `.train()` runs the loop.  wandb / plotting / the validation harness are
+    not part of this build; `synthetic_size: [D, H, W]` in the config trains on synthetic volumes instead of
+    `root_dir`'s GPSRODataset (masks = True)."""
+
+    def __init__(self, config, comm=None):
+        import os
+
+        import torch.nn as nn
+
+        from ..architecture.gpsro import infill3d_gan as dxi
+        from ..comm.distributed import comm as distcomm
+        from ..utils import losses
+        from ..utils import parsing_helpers as ph
+
+        self.config = dict(config)
+        c = self.config
+        self.comm = comm or distcomm(mode="dummy" if "RANK" not in os.environ else "torchrun")   # :48: mode="dummy"
+        self.device = torch.device("cuda", self.comm.local_rank())
+        torch.cuda.set_device(self.device)
+        torch.manual_seed(333)
+
+        def norm_of(key):                                             # :96-112
+            kind = c.get(key, "batch_norm")
+            if kind == "batch_norm":
+                return nn.BatchNorm3d
+            if kind == "instance_norm":
+                return nn.InstanceNorm3d
+            raise NotImplementedError("Error, " + str(kind) + " not supported")
+
+        if c.get("noise_dimensions", 1) <= 0:                         # :147-148
+            raise NotImplementedError("Error, please use at least one noise dimension.")
+        self.noise_type = c.get("noise_type", "Normal")
+        if self.noise_type not in ("Uniform", "Normal"):
+            raise NotImplementedError("Error, noise type {} not supported.".format(self.noise_type))
+        cdt = torch.bfloat16 if c.get("enable_amp", True) else torch.float32     # autocast -> bf16 storage, fp32 accumulate
+        n_in = 1 + c["noise_dimensions"]
+        net = dxi.GAN(input_channels=n_in, output_channels=1, gen_normalizer=norm_of("gen_layer_normalization"),
+                      disc_normalizer=norm_of("disc_layer_normalization"), gen_layer_size=6, disc_layer_size=6)   # :115-119
+        self.generator = net.generator.set_compute_dtype(cdt).to(self.device)
+        self.discriminator = net.discriminator.set_compute_dtype(cdt).to(self.device)
+        lw = c.get("loss_weights", {"valid": 1., "hole": 0.8, "tv": 0.0, "adv": 0.5})
+        if "loss_weights.valid" in c:                                 # the flattened sweep form (:131-132)
+            lw = {k.split(".")[1]: float(v) for k, v in c.items() if k.startswith("loss_weights")}
+        self.loss_weights = {k: float(v) for k, v in lw.items()}
+        g_opt = ph.get_optimizer(self.generator.parameters(), c.get("gen_optimizer", "AdamW"), c.get("gen_start_lr", 1e-3),
+                                 c.get("gen_adam_eps", 1e-8), c.get("gen_weight_decay", 0.01))
+        d_opt = ph.get_optimizer(self.discriminator.parameters(), c.get("disc_optimizer", "AdamW"), c.get("disc_start_lr", 1e-3),
+                                 c.get("disc_adam_eps", 1e-8), c.get("disc_weight_decay", 0.01))
+        g_sched = ph.get_lr_schedule(c["gen_start_lr"], c["gen_lr_schedule"], g_opt) if c.get("gen_lr_schedule") else None
+        d_sched = ph.get_lr_schedule(c["disc_start_lr"], c["disc_lr_schedule"], d_opt) if c.get("disc_lr_schedule") else None
+        self.generator.train(), self.discriminator.train()
+        self.trainer = InfillGANTrainer(
+            self.comm.DistributedModel(self.generator), self.comm.DistributedModel(self.discriminator), g_opt, d_opt,
+            losses.GANLoss("ModifiedMinMax", c["local_batch_size"], self.device),
+            dxi.InpaintingLoss(loss_type=c.get("loss_type", "smooth-l1")), self.loss_weights,
+            gen_warmup_steps=c.get("gen_warmup_steps", 0), disc_acc_min=c.get("disc_acc_min", 0.0),
+            disc_acc_max=c.get("disc_acc_max", 1.0), g_scheduler=g_sched, d_scheduler=d_sched)
+
+    def _batches(self):
+        import os
+
+        from torch.utils.data import DataLoader
+
+        from ..data import gpsro_dataset as gpsro
+        c, dev = self.config, self.device
+        n = c["local_batch_size"]
+        if c.get("synthetic_size"):
+            d, h, w = c["synthetic_size"]
+            g = torch.Generator(device=dev).manual_seed(333 + 7 * self.comm.rank())
+            while True:
+                gt = torch.randn((n, d, h, w), generator=g, device=dev)
+                m = (torch.rand((n, d, h, w), generator=g, device=dev) > 0.3).float()
+                yield gt * m, gt, m, None
+        root = os.path.join(c["root_dir"], "train")
+        ds = gpsro.GPSRODataset(root, statsfile=os.path.join(c["root_dir"], "stats3d.npz"), channels=c.get("channels", list(range(45))),
+                                normalization_type="MinMax" if self.noise_type == "Uniform" else "MeanVariance", shuffle=True,
+                                masks=True, shard_idx=self.comm.rank(), shard_num=self.comm.size(),
+                                num_intra_threads=c.get("max_intra_threads", 1), read_device=dev, send_device=dev)
+        while True:
+            yield from DataLoader(ds, n, drop_last=True)
+
+    def train(self):
+        import datetime as dt
+        c, tr = self.config, self.trainer
+        self.comm.printr('{:14.4f} REPORT: starting training'.format(dt.datetime.now().timestamp()), 0)
+        for inputs_raw, outputs_real, masks_raw, _ in self._batches():
+            inputs_raw, outputs_real, masks_raw = (t.unsqueeze(1) for t in (inputs_raw, outputs_real, masks_raw))   # :273-276
+            shape = (inputs_raw.shape[0], c["noise_dimensions"]) + tuple(inputs_raw.shape[2:])
+            noise = (torch.rand(shape) if self.noise_type == "Uniform" else torch.randn(shape)).to(self.device)      # host draw (:279-283)
+            d_loss, g_loss = tr.step(inputs_raw, outputs_real, masks_raw, noise, comm=self.comm)
+            if tr.step_count % c.get("logging_frequency", 50) == 0 or tr.step_count >= c.get("max_steps", 100):
+                self.comm.printr('{:14.4f} REPORT training: step {} d_loss {} g_loss {} flags {}'.format(
+                    dt.datetime.now().timestamp(), tr.step_count, float(d_loss), float(g_loss), tr.last_flags), 0)
+            if tr.step_count >= c.get("max_steps", 100):
+                break
+        return tr
+
+
+def main(pargs):
+    import yaml
+    if pargs.config_file is not None:
+        with open(pargs.config_file) as f:
+            doc = yaml.safe_load(f)
+        config = dict(doc.get("default", doc))                        # utils/yparams.py: the "default" section
+        config.setdefault("channels", list(range(0, 45)))
+        config["checkpoint"] = pargs.checkpoint
+    else:
+        raise SystemExit("--config_file is required (the reference's wandb-sweep default is not part of this build)")
+    if pargs.run_tag is not None:
+        config["run_tag"] = pargs.run_tag
+    for kv in pargs.set or []:                                        # small overrides: --set max_steps=4 synthetic_size=[16,16,16]
+        k, v = kv.split("=", 1)
+        config[k] = yaml.safe_load(v)
+    return Infill3dGAN(config).train()
+
+
+def build_parser():
+    import argparse as ap
+    AP = ap.ArgumentParser()
+    AP.add_argument("--checkpoint", type=str, default=None, help="Checkpoint file to restart training from.")
+    AP.add_argument("--config_file", type=str, default=None, help="YAML file to read config data from")
+    AP.add_argument("--run_tag", type=str, default=None, help="A tag to identify the run")
+    AP.add_argument("--set", type=str, nargs="*", default=None, help="key=value overrides of the config (YAML values)")
+    return AP
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_known_args()[0])
