@@ -74,10 +74,12 @@ def new_act(n, h, w, c, dtype, device) -> torch.Tensor:
     """Fresh NHWC activation.  The pixel stride is rounded up to a 64-byte multiple (C = 728 bf16:
     1456 -> 1472 bytes) so that the 64-byte K-slabs the GEMM kernels fetch per pixel, and the row
     segments of the element-wise kernels, do not straddle memory sectors; the pad lanes are never
-    read or written (every kernel takes the pixel stride separately from C)."""
+    read or written (every kernel takes the pixel stride separately from C).  Rows of at most half that (the 16
+    field channels in bf16: 32 bytes) stay packed: they tile the 64-byte sectors exactly, and padding them would
+    double the traffic of the layout conversions and of the first convolution's operand."""
     es = 2 if dtype == torch.bfloat16 else 4
     q = ROW_ALIGN_BYTES // es
-    ld = (c + q - 1) // q * q if q else c
+    ld = (c + q - 1) // q * q if q and (2 * c * es > ROW_ALIGN_BYTES or ROW_ALIGN_BYTES % (c * es)) else c
     if ld == c:
         return torch.empty((n, h, w, c), dtype=dtype, device=device)
     return torch.empty((n, h, w, ld), dtype=dtype, device=device)[..., :c]
