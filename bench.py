@@ -190,12 +190,15 @@ def main():
     }
 
     # ---- roofline: one extra (un-timed) step with HIP events around every C-ABI launch
-    if rank == 0 and not args.no_kernel_profile:
-        L.PROFILE = []
+    # (every rank runs the step -- it contains the gradient all-reduces -- rank 0 records)
+    if not args.no_kernel_profile:
+        if rank == 0:
+            L.PROFILE = []
         side, trainer._side = trainer._side, None   # one stream for this step: events then bracket ONE kernel each
         trainer.step(*batches[0])
         torch.cuda.synchronize()
         trainer._side = side
+    if rank == 0 and not args.no_kernel_profile:
         recs, L.PROFILE = L.PROFILE, None
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
