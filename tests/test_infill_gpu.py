@@ -329,3 +329,23 @@ def test_infill3d_gan_module_from_config():
     assert set(tr.last_terms) == {"hole", "valid", "tv", "adv"} and all(torch.isfinite(v) for v in tr.last_terms.values())
     with pytest.raises(NotImplementedError, match="at least one noise dimension"):
         Infill3dGAN(dict(cfg, noise_dimensions=0))
+
+
+def test_infill_nets_with_instance_norm():
+    """gen/disc_layer_normalization: "instance_norm" (infill3d_gan_module.py:96-112): InstanceNorm3d generator and
+    critic against the oracle's restatement (fp32; per-sample statistics over D*H*W rows of the folded volume)."""
+    n, cin, d, h, w, gl, dl = 2, 2, 32, 24, 40, 4, 5
+    gspec, dspec = oi.unet3d_spec(cin, 1, gl, "instance"), oi.disc3d_spec(cin, dl, "instance")
+    PG, PD = oi.fill_state(gspec, 81), oi.fill_state(dspec, 82)
+    G = ig.Generator(layer_size=gl, input_channels=cin, output_channels=1, normalizer=nn.InstanceNorm3d, compute_dtype=F32)
+    D = ig.Discriminator(layer_size=dl, input_channels=cin, normalizer=nn.InstanceNorm3d, compute_dtype=F32)
+    G.load_state_dict(PG), D.load_state_dict(PD)
+    G.to(DEV).train(), D.to(DEV).train()
+    x, gt, mask = oi.synthetic_infill(n, cin, d, h, w, 83)
+    ref, ref_mask = oi.unet3d(PG, x, mask, gl, oi.NormCtx("instance", True))
+    out, out_mask = G(x.to(DEV), mask.to(DEV))
+    assert torch.equal(out_mask.cpu(), ref_mask)
+    close(out.detach().cpu(), ref, 2e-4, "generator, InstanceNorm3d")
+    ref_logits, _ = oi.disc3d(PD, gt[:, :1], mask, dl, oi.NormCtx("instance", True))
+    logits, _ = D(gt[:, :1].to(DEV), mask.to(DEV))
+    close(logits.detach().cpu(), ref_logits, 1e-3, "critic, InstanceNorm3d")
