@@ -34,5 +34,5 @@ json.dump({"source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
                      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES, bench.py --steps 1 --warmup 1, 1152x768x16 batch 8 bf16",
            "kernels": out}, open(sys.argv[2], "w"), indent=1)
 for k, v in sorted(out.items()):
-    print(f"{k:34s} x{v['dispatches']:5d}  mfma/busy {v["mfma_busy_cycles_per_sq_busy_cycle_relative"]:.3f}  wait {v['wait_any_per_wave_cycle']:.2f}  "
+    print(f"{k:34s} x{v['dispatches']:5d}  mfma/busy {v['mfma_busy_cycles_per_sq_busy_cycle_relative']:.3f}  wait {v['wait_any_per_wave_cycle']:.2f}  "
           f"stall {v['wait_inst_per_wave_cycle']:.2f}  active {v['active_inst_per_wave_cycle']:.2f}  lds-conflict {v['lds_conflict_per_lds_active']:.3f}")
