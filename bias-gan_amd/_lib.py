@@ -116,7 +116,7 @@ _SIGS = {
                      c_f32, c_vp],
     "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
 }
-EXPORTS = sorted(list(_SIGS) + list(_HOST_SIGS) + ["bg_last_error", "bg_conv_weight_kpad"])
+EXPORTS = sorted(list(_SIGS) + list(_HOST_SIGS) + ["bg_last_error", "bg_conv_weight_kpad", "bg_conv_set_variant"])
 
 _lib = None
 
@@ -143,6 +143,8 @@ def load():
     lib.bg_last_error.restype = C.c_char_p
     lib.bg_conv_weight_kpad.argtypes = [c_i32]
     lib.bg_conv_weight_kpad.restype = c_i32
+    lib.bg_conv_set_variant.argtypes = [c_i32]
+    lib.bg_conv_set_variant.restype = c_i32
     if lib.bg_abi_version() != ABI_VERSION:
         raise RuntimeError("bias_gan_amd: libbgamd.so ABI version mismatch; rebuild")
     _lib = lib
@@ -152,6 +154,12 @@ def load():
 def kpad(dtype: torch.dtype) -> int:
     """Reduction-dimension padding granule of the packed conv weight copies."""
     return load().bg_conv_weight_kpad(dt(dtype))
+
+
+def conv_variant(v: int) -> None:
+    """GEMM tile family of the conv launches: -1 heuristics, 0 classic tiles only, 2 fat tiles wherever legal."""
+    if load().bg_conv_set_variant(int(v)) != 0:
+        raise RuntimeError(f"bg_conv_set_variant({v}): {_lib.bg_last_error().decode()}")
 
 
 def dt(dtype: torch.dtype) -> int:

@@ -104,17 +104,30 @@ class comm(object):
             if not dist.is_initialized():
                 dist.init_process_group(backend=backend)
             return
-        if mode == "openmpi":
-            raise RuntimeError("the 'mpi' backend is not part of this build; launch with torch.distributed.run "
-                               "(RANK/WORLD_SIZE in the environment) or use mode='openmpi-nccl' / 'dummy'")
-        elif mode == "openmpi-nccl":
-            addrport = os.getenv("PMIX_SERVER_URI2").split("//")[1]
-            os.environ["MASTER_ADDR"] = addrport.split(":")[0]
+        if mode in ("openmpi", "openmpi-nccl"):
+            # The reference's default "openmpi" hands the collectives to MPI (comm/distributed.py:45-47); here every
+            # multi-process mode runs over RCCL, and the launcher's environment only supplies rank / size / address:
+            # mpirun (OMPI_COMM_WORLD_*, PMIX_SERVER_URI2 for the address, single node like the reference's
+            # "openmpi-nccl", :49-56).  Without any launcher it is one process -- MPI's singleton init -- and needs
+            # no process group.
+            if "OMPI_COMM_WORLD_SIZE" not in os.environ:
+                os.environ.setdefault("MASTER_ADDR", "localhost")
+                return
+            uri = os.getenv("PMIX_SERVER_URI2")
+            if uri and "//" in uri:
+                os.environ["MASTER_ADDR"] = uri.split("//")[1].split(":")[0]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             comm_rank = int(os.getenv('OMPI_COMM_WORLD_RANK', 0))
-            comm_size = int(os.getenv("OMPI_COMM_WORLD_SIZE", 0))
-            dist.init_process_group(backend="nccl", rank=comm_rank, world_size=comm_size)
+            comm_size = int(os.getenv("OMPI_COMM_WORLD_SIZE", 1))
+            backend = os.environ.get("BGAMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            if torch.cuda.is_available():
+                torch.cuda.set_device(int(os.getenv("OMPI_COMM_WORLD_LOCAL_RANK", comm_rank)) % max(1, torch.cuda.device_count()))
+            if not dist.is_initialized():
+                dist.init_process_group(backend=backend, rank=comm_rank, world_size=comm_size)
         elif mode == "dummy":
             os.environ.setdefault("MASTER_ADDR", "localhost")
+        else:
+            raise ValueError("comm: unknown mode {!r} (openmpi, openmpi-nccl, dummy)".format(mode))
 
     def metric_average(self, val, name=None, op_name=None, device=None):
         """SUM over ranks (times 1/size when op_name == 'average'), returned as a

@@ -54,7 +54,21 @@ struct GemmConvParams {
     int w_bytes;
     float* ws;         // split-K: fp32 [splits][M][NO]; every split stores its partial tile into its own slice
     int kt_per_split;  // split-K: K-steps per split
+    // fat-tile variant: pixel tiles of tn_valid (<= the template's padded width) rows, tiles_per_group of them per
+    // statistic group of group_pix pixels (one group = the whole tensor unless stat_group_pix is set)
+    int tn_valid, tiles_per_group, group_pix;
+#ifdef BG_STAMPS   // diagnostic build only (scripts/stamps_fat.py): 8 time stamps per workgroup
+    unsigned long long* dbg;
+#endif
 };
+#ifdef BG_STAMPS
+unsigned long long* g_dbg_stamps = nullptr;
+#define BG_STAMP(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(long long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define BG_STAMP_CYC(i) do { if (P.dbg && threadIdx.x == 0) P.dbg[(long long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BG_STAMP(i)
+#define BG_STAMP_CYC(i)
+#endif
 
 template <int BKB>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -613,6 +627,438 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
 }
 
 
+// ------------------------------------------------------- fat-tile variant ----
+// ONE 512-thread workgroup per CU whose staging ring is the CU's whole 160 KiB of LDS, 8 waves as WM x WN, each
+// wave an (MI*16) x (NJ*16) sub-tile of MI x NJ accumulators (96 x 112 = 168 VGPRs at MI 6, NJ 7).  Compared with
+// the 64 x 64-per-wave tiles above: 13 fragment reads for 42 MFMAs instead of 8 for 16 (LDS read traffic per FLOP
+// 0.6x), 5 LDS-DMA pieces per wave for 42 MFMAs instead of 3 for 16 (DMA issue per FLOP 0.63x), operand bytes through
+// the DMA path per FLOP 0.6x (384 x 224: 141 FLOP/B against 85 for 256 x 128), and one barrier per 42 MFMAs.
+// The pixel width of a tile is a RUN-TIME number tn_valid <= NJ*WN*16 (rows beyond it are fetched as out-of-range
+// zeros and not stored), chosen by the launcher so that the tile count is a whole number of rounds of the 256 CUs:
+// 8 x 72 x 48 pixels x 728 channels = 2 x 128 tiles of 384 x 216 -- one per CU -- where 256 x 128 tiles needed two
+// rounds for 1.27 rounds of work.  Staging: A rows [s*128 + wave*16, +16) and B rows likewise per slot s, so every
+// wave issues the same SA + SB pieces per K-step (uniform counted waits); B slots beyond the tile are dummies.
+template <typename T, int BKB, int MI, int NJ>
+__device__ __forceinline__ void mma_fat(const char* sA, const char* sB, int rowA, int rowB, int lane, f32x4 (&acc)[MI][NJ]) {
+    const int r16 = lane & 15, q = lane >> 4;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < BKB / 64; ++ks) {
+            bf16x8 b[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + i * 16 + r16, ks * 4 + q));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < BKB / 16; ++kk) {
+            float b[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float*>(sB + lds_off<BKB>(rowB + j * 16 + r16, kk) + q * 4);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const float a = *reinterpret_cast<const float*>(sA + lds_off<BKB>(rowA + i * 16 + r16, kk) + q * 4);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Epilogue of the fat tile.  A lane's accumulators are 4 consecutive channels of one pixel: stored as they stand, a
+// wave instruction writes sixteen 32-byte pieces of sixteen pixel rows, and the memory side sees every 128-byte line of
+// the output four times (measured with in-kernel stamps: 10 us of a 39 us launch for 40 MB; 16 us when the four pieces
+// of a line were issued seven instructions apart).  So each wave transposes its sub-tile through a private LDS region,
+// one 16-pixel block at a time (the staging ring is free by then): ds_write in accumulator layout, ds_read_b128 so that
+// a lane holds 16 contiguous bytes of a pixel row and a pixel's MI*32 bytes are written as ONE run by consecutive lanes.
+// Stores go through a buffer descriptor REBASED to the tile's first pixel (64-bit base per workgroup, small 32-bit
+// offsets: no 2 GiB limit on the tensor); invalid rows / channels carry the out-of-range marker and are dropped by the
+// hardware: no exec-mask branches, no 64-bit address arithmetic per store.  Statistics need no masks either: rows
+// beyond the tile and channels beyond Cout accumulated zeros.
+template <typename T, int MI, int NJ, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4 (&acc)[MI][NJ], int p_base, int rows_valid,
+                                                  int grp, int c_base, int wave_c, int wave_p, int lane, char* smem) {
+    constexpr int TM = WM * MI * 16, ES = (int)sizeof(T);
+    constexpr int CHB = MI * 16 * ES;      // bytes of one pixel's channels in this wave's sub-tile
+    constexpr int ROWB = CHB + 16;         // padded LDS row
+    constexpr int CPP = CHB / 16;          // 16-byte chunks per pixel
+    constexpr int NST = 16 * CPP / 64;     // store instructions per 16-pixel block
+    constexpr int REGION = 16 * ROWB;
+    static_assert((16 * CPP) % 64 == 0, "a 16-pixel block must be whole wave instructions");
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wave = wave_c * WN + wave_p;
+    T* out_tile = reinterpret_cast<T*>(P.out) + (long long)p_base * P.ldo;
+    const long long rem = (((long long)P.M - p_base - 1) * P.ldo + P.NO) * ES;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
+    const bool stats = P.stat_sum != nullptr;
+    char* region = smem + wave * REGION;                               // this wave's transposition buffer
+    float* red = reinterpret_cast<float*>(smem + 8 * REGION);         // [wave_p][TM channels][2]
+    static_assert(8 * REGION + WN * TM * 8 <= 64 * 1024, "epilogue scratch");
+    __syncthreads();   // every wave is done reading the staging ring: reuse it
+
+    // read-back geometry: chunk ci of the block's 16 * CPP is (pixel ci / CPP, 16-byte chunk ci % CPP)
+    int rd_off[NST], st_coff[NST], st_pix[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int ci = t * 64 + lane;
+        const int pix = ci / CPP, ch = ci - pix * CPP;
+        rd_off[t] = pix * ROWB + ch * 16;
+        const int co = c_base + wave_c * MI * 16 + ch * (16 / ES);
+        st_coff[t] = co < P.NO ? co * ES : OOB;      // Cout is a multiple of the 16-byte vector
+        st_pix[t] = wave_p * NJ * 16 + pix;
+    }
+    f32x4 bv[MI];
+    if (P.bias) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int co = c_base + wave_c * MI * 16 + i * 16 + q * 4;
+            bv[i] = co < P.NO ? *reinterpret_cast<const f32x4*>(P.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    float s1[MI][4], s2[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
+    const int wr_off = r16 * ROWB + q * 4 * ES;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            f32x4 v = acc[i][j];
+            if (P.bias) v += bv[i];
+            if constexpr (sizeof(T) == 2) {
+                const bf16x4 ov = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(region + wr_off + i * 16 * ES) = ov;
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = (float)ov[e];
+                        s1[i][e] += r;
+                        s2[i][e] = fmaf(r, r, s2[i][e]);
+                    }
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(region + wr_off + i * 16 * ES) = v;
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[i][e] += v[e];
+                        s2[i][e] = fmaf(v[e], v[e], s2[i][e]);
+                    }
+                }
+            }
+        }
+        // the region is private to the wave and a wave's LDS instructions execute in order: no barrier
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(region + rd_off[t]);
+            const int row = st_pix[t] + j * 16;
+            const int roff = row < rows_valid ? row * P.ldo * ES : OOB;
+            const int off = (roff | st_coff[t]) < 0 ? OOB : roff + st_coff[t];
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, off, 0, 0);
+        }
+    }
+    if (stats) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[i][e] = row16_sum(s1[i][e]);
+                s2[i][e] = row16_sum(s2[i][e]);
+            }
+        if (r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cl = wave_c * MI * 16 + i * 16 + q * 4 + e;
+                    red[(wave_p * TM + cl) * 2 + 0] = s1[i][e];
+                    red[(wave_p * TM + cl) * 2 + 1] = s2[i][e];
+                }
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < TM && c_base + t < P.NO) {
+            const long long o = (long long)grp * P.NO + c_base + t;
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wp = 0; wp < WN; ++wp) {
+                a1 += red[(wp * TM + t) * 2];
+                a2 += red[(wp * TM + t) * 2 + 1];
+            }
+            atomicAdd(P.stat_sum + o, (double)a1);
+            atomicAdd(P.stat_sq + o, (double)a2);
+        }
+    }
+}
+
+// PW1: a single tap (1x1 convolutions): the address set-up runs once and its registers are free in the K loop.
+// BKB: bytes of K per row and K-step.  128 = whole cache lines per row (a 1-KiB DMA piece is 8 rows x 128 B), two
+// stages of 80 KiB: a stage is issued right after the barrier that retires its predecessor and has the 84 MFMAs per wave
+// of that step to land.  64 = half lines (16 rows x 64 B per piece; the other half of every line is fetched again by the
+// next K-step), four stages, two steps in flight across each barrier.
+template <typename T, int BKB, int MI, int NJ, int WM, int WN, int NBUF, bool PW1>
+__global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BK = BKB / ES;
+    constexpr int CPR = BKB / 16;          // 16-byte chunks per row
+    constexpr int RPG = 64 / CPR;          // rows per DMA piece: 16 or 8
+    constexpr int PPS = 16 / RPG;          // pieces per 16-row slot: 1 or 2
+    constexpr int TM = WM * MI * 16, TN = WN * NJ * 16;
+    constexpr int SA = TM / 128, SB = (TN + 127) / 128;   // 16-row slots per wave and K-step
+    constexpr int GROUP = (SA + SB) * PPS;                // DMA pieces per wave and K-step
+    constexpr int A_BYTES = TM * BKB, STAGE_BYTES = (TM + SB * 128) * BKB;
+    constexpr int DIST = NBUF - 1;
+    static_assert(BKB == 64 || BKB == 128, "64- or 128-byte rows");
+    static_assert(WM * WN == 8 && TM % 128 == 0, "8 waves; A rows in 128-row slots");
+    static_assert(DIST >= 1 && DIST <= 3, "counted waits are written for 1 to 3 K-steps of prefetch");
+    static_assert(NBUF * STAGE_BYTES <= 160 * 1024, "staging ring exceeds the LDS");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_c = wave / WN, wave_p = wave % WN;
+
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tile_c = bid % P.tiles_c, tile_p = bid / P.tiles_c;
+    const int grp = tile_p / P.tiles_per_group, tig = tile_p - grp * P.tiles_per_group;
+    const int p_base = grp * P.group_pix + tig * P.tn_valid;
+    const int rows_valid = min(P.tn_valid, P.group_pix - tig * P.tn_valid);   // >= 1 (launcher)
+    const int c_base = tile_c * TM;
+    const int RS = P.KH * P.KW;
+
+    // Activation descriptor REBASED to the first source row this tile can touch (64-bit base per workgroup): offsets are
+    // relative to it and small, so the operand may be larger than 2 GiB.  Every source pixel of a pixel p >= p_base lies
+    // at or behind the start of row max(0, first tap row of p_base) of p_base's image.
+    const unsigned ohw_ = (unsigned)(P.OH * P.OW);
+    const int n0 = (int)((unsigned)p_base / ohw_);
+    const int oh0 = (int)(((unsigned)p_base - (unsigned)n0 * ohw_) / (unsigned)P.OW);
+    int row0c;
+    if (!P.transposed) row0c = max(0, oh0 * P.stride - P.pad);
+    else { const int t0 = oh0 + P.pad - (P.KH - 1) * P.dil; row0c = t0 <= 0 ? 0 : t0 / P.stride; }
+    const long long base_pix = ((long long)n0 * P.IH + row0c) * P.IW;
+    const long long in_rem = (((long long)P.N * P.IH * P.IW - base_pix - 1) * P.ldi + P.CK) * ES;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(reinterpret_cast<const T*>(P.in) + base_pix * P.ldi), 0, (int)(in_rem < 0x7fffffffLL ? in_rem : 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.w), 0, P.w_bytes, 0x00020000);
+
+    const int lr = lane / CPR, lc = lane % CPR;
+    // Source-side swizzle (the LDS image of a DMA is lane-linear).  Slots start on multiples of 16 rows and pieces on
+    // multiples of RPG, so a lane's source chunk depends on the piece's position inside its slot only.
+    int chk[PPS];
+    bool tail_cut[PPS];   // see gemm_conv_kernel
+    const int ksteps_per_tap = (P.CK + BK - 1) / BK;
+#pragma unroll
+    for (int h = 0; h < PPS; ++h) {
+        const int row = h * RPG + lr;   // row inside the 16-row slot
+        chk[h] = ((BKB == 64) ? (lc ^ ((0 - (row >> 2)) & 3)) : (lc ^ ((row >> 1) & 7))) * 16;
+        tail_cut[h] = (ksteps_per_tap - 1) * BK + chk[h] / ES >= P.CK;
+    }
+    int w_base[SA][PPS], pix_base[SB][PPS], pix_n[SB][PPS], pix_h[SB][PPS], pix_w[SB][PPS];
+    bool pix_ok[SB][PPS];
+    const bool direct = !P.transposed || P.stride == 1;
+    const int sgn = P.transposed ? -1 : 1;
+#pragma unroll
+    for (int s = 0; s < SA; ++s)
+#pragma unroll
+        for (int h = 0; h < PPS; ++h) {
+            const int co = c_base + s * 128 + wave * 16 + h * RPG + lr;
+            w_base[s][h] = co < P.NO ? co * RS * P.CKp * ES + chk[h] : OOB;
+        }
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+#pragma unroll
+        for (int h = 0; h < PPS; ++h) {
+            const int row = s * 128 + wave * 16 + h * RPG + lr;
+            pix_ok[s][h] = row < rows_valid;
+            const unsigned pp = pix_ok[s][h] ? (unsigned)(p_base + row) : 0u;
+            const unsigned ohw = (unsigned)(P.OH * P.OW);
+            const unsigned n = pp / ohw;
+            const unsigned rem = pp - n * ohw;
+            const unsigned qq = rem / (unsigned)P.OW;
+            const int oh = (int)qq, ow = (int)(rem - qq * (unsigned)P.OW);
+            pix_n[s][h] = (int)n - n0;   // relative to the rebased descriptor
+            if (!P.transposed) {
+                pix_h[s][h] = oh * P.stride - P.pad;
+                pix_w[s][h] = ow * P.stride - P.pad;
+            } else {
+                pix_h[s][h] = oh + P.pad;
+                pix_w[s][h] = ow + P.pad;
+            }
+            pix_base[s][h] = ((pix_n[s][h] * P.IH + pix_h[s][h] - row0c) * P.IW + pix_w[s][h]) * P.ldi * ES + chk[h];
+        }
+
+    const int KT = RS * ksteps_per_tap;
+    int l_tap_r = 0, l_tap_s = 0, l_ks = 0, l_tap = 0;
+    int va[SA][PPS], vb[SB][PPS];
+    auto start_tap = [&]() {
+        const int dh = sgn * l_tap_r * P.dil, dw_ = sgn * l_tap_s * P.dil;
+        const int tap_delta = (dh * P.IW + dw_) * P.ldi * ES;
+#pragma unroll
+        for (int s = 0; s < SA; ++s)
+#pragma unroll
+            for (int h = 0; h < PPS; ++h) va[s][h] = w_base[s][h] == OOB ? OOB : w_base[s][h] + l_tap * P.CKp * ES;
+#pragma unroll
+        for (int s = 0; s < SB; ++s)
+#pragma unroll
+            for (int h = 0; h < PPS; ++h) {
+                if (direct) {
+                    const int ih = pix_h[s][h] + dh, iw = pix_w[s][h] + dw_;
+                    const bool ok = pix_ok[s][h] && (unsigned)ih < (unsigned)P.IH && (unsigned)iw < (unsigned)P.IW;
+                    vb[s][h] = ok ? pix_base[s][h] + tap_delta : OOB;
+                } else {
+                    const int th = pix_h[s][h] - l_tap_r * P.dil, tw = pix_w[s][h] - l_tap_s * P.dil;
+                    bool ok = pix_ok[s][h] && th >= 0 && tw >= 0;
+                    const int ih = th / P.stride, iw = tw / P.stride;
+                    ok = ok && (ih * P.stride == th) && (iw * P.stride == tw) && ih < P.IH && iw < P.IW;
+                    vb[s][h] = ok ? ((pix_n[s][h] * P.IH + ih - row0c) * P.IW + iw) * P.ldi * ES + chk[h] : OOB;
+                }
+            }
+    };
+    if (PW1) start_tap();
+    // One K-step's staging = GROUP pieces per wave.  issue_begin()/issue_end() carry the (scalar) tap bookkeeping,
+    // piece(buf, pi) issues piece pi: the A slots' pieces first, then the B slots'.
+    bool last_ks = false;
+    auto issue_begin = [&]() {
+        if (!PW1 && l_ks == 0) start_tap();
+        last_ks = l_ks == ksteps_per_tap - 1;
+    };
+    auto piece = [&](int buf, int pi) {   // pi is a compile-time constant at every call site (unrolled loops)
+        char* stage_a = smem + buf * STAGE_BYTES + wave * 16 * BKB;
+        if (pi < SA * PPS) {
+            const int s_ = pi / PPS, h = pi % PPS;
+            dma16(rs_w, stage_a + (s_ * 128 + h * RPG) * BKB, va[s_][h]);
+            va[s_][h] += BKB;   // an out-of-range marker stays out of range
+        } else {
+            const int s_ = (pi - SA * PPS) / PPS, h = (pi - SA * PPS) % PPS;
+            dma16(rs_in, stage_a + A_BYTES + (s_ * 128 + h * RPG) * BKB, (last_ks && tail_cut[h]) ? OOB : vb[s_][h]);
+            vb[s_][h] += BKB;
+        }
+    };
+    auto issue_end = [&]() {
+        if (++l_ks == ksteps_per_tap) {
+            l_ks = 0;
+            ++l_tap;
+            if (++l_tap_s == P.KW) { l_tap_s = 0; ++l_tap_r; }
+        }
+    };
+    auto issue = [&](int buf) {
+        issue_begin();
+#pragma unroll
+        for (int pi = 0; pi < GROUP; ++pi) piece(buf, pi);
+        issue_end();
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    BG_STAMP(0);
+    issue(0);
+    if (DIST >= 2 && KT > 1) issue(1);
+    if (DIST >= 3 && KT > 2) issue(2);
+    BG_STAMP(1);
+    // In the loop the pieces of stage kt+DIST are issued BETWEEN the MFMA groups of step kt (one group = the NJ MFMAs
+    // of one A fragment), PPG per group, instead of as a burst behind the barrier: a wave sits ~100-150 cycles in the
+    // issue of one piece, and with the burst both waves of a SIMD did so at the same time with the matrix pipe idle
+    // (measured with in-kernel stamps: a K-step took its MFMA time PLUS its issue time).  Spread out, one wave's issue
+    // stall is the other's MFMA slot.
+    constexpr int NGRP = (sizeof(T) == 2 ? BKB / 64 : BKB / 16) * MI;   // MFMA groups per K-step
+    constexpr int PPG = NBUF == 2 ? (GROUP + NGRP / 2 - 1) / (NGRP / 2) : (GROUP + NGRP - 1) / NGRP;   // a two-stage ring's pieces
+                                                                  // must land within this step: all in its first half
+    static_assert(PPG * NGRP >= GROUP, "not enough MFMA groups to carry the pieces");
+    const int r16 = lane & 15, q = lane >> 4;
+    const int rowA = wave_c * MI * 16, rowB = wave_p * NJ * 16;
+    int buf = 0, nbuf = DIST % NBUF;
+    for (int kt = 0; kt < KT; ++kt) {
+#ifdef BG_STAMPS
+        if (kt == 1) { BG_STAMP(2); BG_STAMP_CYC(6); }
+#endif
+        // retire this wave's pieces of step kt (the later steps' stay in flight), then meet the other waves
+        const int ahead = KT - 1 - kt;
+        if (DIST >= 3 && ahead >= 2) wait_vmcnt<2 * GROUP>();
+        else if (DIST >= 2 && ahead >= 1) wait_vmcnt<GROUP>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        // stage kt+DIST: its ring slot was last read in iteration kt-1, which every wave has left
+        const bool more = kt + DIST < KT;
+        if (more) issue_begin();
+        const char* sA = smem + buf * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < BKB / 64; ++ks) {
+                bf16x8 b[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q));
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + r16, ks * 4 + q));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+#pragma unroll
+                        for (int e = 0; e < PPG; ++e)
+                            if ((ks * MI + i) * PPG + e < GROUP) piece(nbuf, (ks * MI + i) * PPG + e);
+                    }
+                    bf16x8 an = a;
+                    if (i + 1 < MI) an = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + (i + 1) * 16 + r16, ks * 4 + q));
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    a = an;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BKB / 16; ++kk) {
+                float b[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float*>(sB + lds_off<BKB>(rowB + j * 16 + r16, kk) + q * 4);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+#pragma unroll
+                        for (int e = 0; e < PPG; ++e)
+                            if ((kk * MI + i) * PPG + e < GROUP) piece(nbuf, (kk * MI + i) * PPG + e);
+                    }
+                    const float a = *reinterpret_cast<const float*>(sA + lds_off<BKB>(rowA + i * 16 + r16, kk) + q * 4);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue_end();
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+        nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
+    }
+    BG_STAMP(3);
+    BG_STAMP_CYC(7);
+    conv_epilogue_fat<T, MI, NJ, WM, WN>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
+#ifdef BG_STAMPS
+    BG_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BG_STAMP(5);
+#endif
+}
+
 // y[r][c] = T(sum_s ws[s][r][c]), splits summed in index order (deterministic)
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, long long rows, int C, T* y, int ldy) {
@@ -999,6 +1445,75 @@ int check_conv_desc(const bg_conv_desc* d, const char* who) {
     return BG_OK;
 }
 
+// Tuning / test hook (bg_conv_set_variant): -1 = by environment and heuristics, 0 = the 64 x 64-per-wave tiles only,
+// 2 = the fat-tile kernel wherever it is legal (small test shapes included).
+int g_conv_variant = -1;
+
+template <typename T, int BKB, int MI, int NJ, int WM, int WN, int NBUF, bool PW1>
+int launch_fat(const GemmConvParams& P, long long nblk, hipStream_t st) {
+    constexpr int SB = (WN * NJ * 16 + 127) / 128;
+    constexpr int SH = NBUF * (WM * MI * 16 + SB * 128) * BKB;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_fat_kernel<T, BKB, MI, NJ, WM, WN, NBUF, PW1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SH);
+        once = true;
+    }
+#ifdef BG_STAMPS
+    GemmConvParams Q = P;
+    Q.dbg = g_dbg_stamps;
+    hipLaunchKernelGGL((gemm_conv_fat_kernel<T, BKB, MI, NJ, WM, WN, NBUF, PW1>), dim3((unsigned)nblk), dim3(512), SH, st, Q);
+#else
+    hipLaunchKernelGGL((gemm_conv_fat_kernel<T, BKB, MI, NJ, WM, WN, NBUF, PW1>), dim3((unsigned)nblk), dim3(512), SH, st, P);
+#endif
+    BG_CHECK_LAUNCH("gemm_conv_fat_kernel");
+    return BG_OK;
+}
+
+// Fat-tile plan: out-channel tile 384 (1x1 convolutions only: its 168 accumulator registers leave no room for the
+// tap bookkeeping), 256 or 128 rows (Cout <= 128), pixel tiles of at most 224 rows (112 for a 256-row tile when the
+// wider one would leave half the chip idle).  The cost of a candidate is rounds-of-256-tiles x MFMA work per tile;
+// the pixel width is then shrunk until the tiles fill their last round.  Returns 0 when the launch should stay on the
+// 64 x 64-per-wave kernels, else 1000 * rows + padded pixel width.
+template <typename T>
+int plan_fat(GemmConvParams& P, bool big) {   // big: an operand beyond the classic kernels' 32-bit offsets -> fat tiles always
+    static const int fat_env = getenv("BGAMD_FAT") ? atoi(getenv("BGAMD_FAT")) : 1;
+    static const int fat128 = getenv("BGAMD_FAT128") ? atoi(getenv("BGAMD_FAT128")) : 0;   // A/B: 128-row tiles by heuristics too
+    const int mode = g_conv_variant >= 0 ? g_conv_variant : fat_env;
+    if (mode == 0 && !big) return 0;
+    const int bk = 64 / (int)sizeof(T);
+    const long long kt = (long long)P.KH * P.KW * ((P.CK + bk - 1) / bk);
+    if (mode != 2 && !big && ((P.NO <= 128 && !fat128) || kt < 8 || P.M < 16384)) return 0;
+    const int groups = P.stat_group_pix ? (int)(P.M / P.stat_group_pix) : 1;
+    const long long gp = P.M / groups;
+    if (gp * groups != P.M || gp >= (1LL << 31)) return 0;
+    const bool pw1 = P.KH * P.KW == 1;
+    constexpr int NCU = 256;
+    static const int cand[4][2] = {{384, 224}, {256, 224}, {256, 112}, {128, 224}};
+    int best = -1;
+    long long best_cost = 0, best_rounds = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int tm = cand[c][0], tnp = cand[c][1];
+        if (tm == 384 && !pw1) continue;
+        if ((tm == 128) != (P.NO <= 128)) continue;
+        const long long tc = (P.NO + tm - 1) / tm, tp0 = groups * ((gp + tnp - 1) / tnp);
+        const long long rounds = (tc * tp0 + NCU - 1) / NCU, cost = rounds * tm * tnp;
+        if (best < 0 || cost < best_cost) { best = c; best_cost = cost; best_rounds = rounds; }   // ties: the larger tile, listed first
+    }
+    const int tm = cand[best][0], tnp = cand[best][1];
+    P.tiles_c = (P.NO + tm - 1) / tm;
+    long long tpg = (gp + tnp - 1) / tnp;                            // pixel tiles per group, at least
+    const long long fill = best_rounds * NCU / P.tiles_c / groups;   // ... and as many as the last round has room for
+    if (fill > tpg) tpg = fill;
+    long long tnv = (gp + tpg - 1) / tpg;
+    tpg = (gp + tnv - 1) / tnv;                                      // no empty tiles
+    P.tn_valid = (int)tnv;
+    P.tiles_per_group = (int)tpg;
+    P.group_pix = (int)gp;
+    P.tiles_p = (int)(tpg * groups);
+    return tm * 1000 + tnp;
+}
+
 template <typename T>
 int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
     GemmConvParams P = P0;
@@ -1006,12 +1521,41 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
     P.CKp = pad_k(P.CK, dt);
     const long long in_bytes = (((long long)P.N * P.IH * P.IW - 1) * P.ldi + P.CK) * (long long)sizeof(T);
     const long long w_bytes = (long long)P.NO * P.KH * P.KW * P.CKp * (long long)sizeof(T);
-    if (in_bytes >= (1LL << 31) || w_bytes >= (1LL << 31)) {
+    const long long out_bytes = ((P.M - 1) * P.ldo + P.NO) * (long long)sizeof(T);
+    // The fat-tile kernel rebases its activation / output descriptors per tile; the 64 x 64-per-wave kernels address
+    // the whole activation with 32-bit offsets.
+    const bool big = in_bytes >= (1LL << 31) || out_bytes >= (1LL << 31);
+    if (w_bytes >= (1LL << 31) || (big && splits != 1)) {
         bg_set_error("conv: operand larger than 2 GiB (32-bit buffer offsets)");
         return BG_E_ARG;
     }
-    P.in_bytes = (int)in_bytes;
+    P.in_bytes = big ? 0 : (int)in_bytes;
     P.w_bytes = (int)w_bytes;
+    if (splits == 1) {
+        const int plan = plan_fat<T>(P, big);
+        if (plan) {
+            const int tm = plan / 1000, tnp = plan % 1000;
+            const long long nblk = (long long)P.tiles_c * P.tiles_p;
+            const bool pw1 = P.KH * P.KW == 1;
+            static const int fat_bkb = getenv("BGAMD_FAT_BKB") ? atoi(getenv("BGAMD_FAT_BKB")) : 128;   // A/B: 64 = half-line rows, 4 stages
+            if (tm == 128) {
+                if (pw1) return launch_fat<T, 128, 2, 7, 4, 2, 3, true>(P, nblk, st);
+                return launch_fat<T, 128, 2, 7, 4, 2, 3, false>(P, nblk, st);
+            }
+            if (tnp == 112) {   // 256 x 112: 8 waves along the channels, every wave all 112 pixels
+                if (pw1) return launch_fat<T, 128, 2, 7, 8, 1, 3, true>(P, nblk, st);
+                return launch_fat<T, 128, 2, 7, 8, 1, 3, false>(P, nblk, st);
+            }
+            if (fat_bkb == 64) {
+                if (tm == 384) return launch_fat<T, 64, 6, 7, 4, 2, 4, true>(P, nblk, st);
+                if (pw1) return launch_fat<T, 64, 4, 7, 4, 2, 4, true>(P, nblk, st);
+                return launch_fat<T, 64, 4, 7, 4, 2, 4, false>(P, nblk, st);
+            }
+            if (tm == 384) return launch_fat<T, 128, 6, 7, 4, 2, 2, true>(P, nblk, st);
+            if (pw1) return launch_fat<T, 128, 4, 7, 4, 2, 2, true>(P, nblk, st);
+            return launch_fat<T, 128, 4, 7, 4, 2, 2, false>(P, nblk, st);
+        }
+    }
     if (splits > 1) {   // split-K (few tiles, long reduction): 128 x 128 tiles, (tiles x splits) blocks, one workspace slice each
         const int kt_all = P.KH * P.KW * ((P.CK + 64 / (int)sizeof(T) - 1) / (64 / (int)sizeof(T)));
         P.kt_per_split = (kt_all + splits - 1) / splits;
@@ -1290,6 +1834,16 @@ extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const 
     }
     BG_CHECK_LAUNCH("wgrad_kernel");
     if (dbias) return bg_colsum(d->dtype, dy, d->ldy, P.M, d->Cout, 1, 1.0f, dbias, stream);
+    return BG_OK;
+}
+
+#ifdef BG_STAMPS
+extern "C" int bg_conv_debug_stamps(void* buf) { g_dbg_stamps = (unsigned long long*)buf; return BG_OK; }
+#endif
+
+extern "C" int bg_conv_set_variant(int32_t variant) {
+    BG_CHECK_ARG(variant == -1 || variant == 0 || variant == 2, "bg_conv_set_variant: %d is not one of -1, 0, 2", variant);
+    g_conv_variant = variant;
     return BG_OK;
 }
 

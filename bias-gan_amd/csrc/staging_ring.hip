@@ -389,6 +389,20 @@ extern "C" int bg_ring_release(bg_ring* r, int64_t ticket, void* consumer_stream
     Slot* s = find_slot(r, ticket);
     BG_CHECK_ARG(s != nullptr, "bg_ring_release: unknown ticket %lld", (long long)ticket);
     r->cv_slots.wait(lk, [&] { return s->state >= 2; });  // never free a slot that workers still write
+    if (r->device >= 0 && s->state == 2) {
+        // The H2D copy of this ticket reads the PINNED HOST half of the slot asynchronously.  The stream waits above
+        // order the device half only; the next submit's worker threads pread() into s->host as soon as the slot is
+        // free, so the host must see that copy finished before the slot changes hands (the slot stays 'in use'
+        // meanwhile, nobody else touches it; the wait is outside the lock so the workers of other slots keep going).
+        hipEvent_t ev = s->ev;
+        lk.unlock();
+        const hipError_t e = hipEventSynchronize(ev);
+        lk.lock();
+        if (e != hipSuccess) {
+            bg_set_error("bg_ring_release: waiting for the H2D copy of ticket %lld: %s", (long long)ticket, hipGetErrorString(e));
+            return BG_E_LAUNCH;
+        }
+    }
     s->state = 0;
     s->ticket = -1;
     return BG_OK;

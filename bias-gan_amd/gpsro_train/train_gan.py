@@ -315,9 +315,16 @@ def main(pargs):
     d_opt = ph.get_optimizer(discriminator.parameters(), pargs.optimizer_discriminator, pargs.start_lr_discriminator,
                              pargs.adam_eps, pargs.weight_decay)
     generator.train(), discriminator.train()
-    g_sched = ph.get_lr_schedule(pargs.start_lr_generator, pargs.lr_schedule_generator, g_opt) \
+    # The reference's order (train_gan.py:163-173): restore nets and optimisers FIRST, then build the schedules with
+    # last_step = the restored step -- the optimiser state carries the already decayed 'lr', and a schedule started at
+    # -1 would count the passed milestones (or the cosine phase) a second time.
+    start_step, start_epoch = 0, 0
+    if pargs.checkpoint:
+        generator.arena(), discriminator.arena()   # the optimiser moments are flat buffers over the parameter arenas
+        start_step, start_epoch = comm.init_gan_training_state(generator, discriminator, g_opt, d_opt, pargs.checkpoint, device)
+    g_sched = ph.get_lr_schedule(pargs.start_lr_generator, pargs.lr_schedule_generator, g_opt, last_step=start_step) \
         if pargs.lr_schedule_generator else None
-    d_sched = ph.get_lr_schedule(pargs.start_lr_discriminator, pargs.lr_schedule_discriminator, d_opt) \
+    d_sched = ph.get_lr_schedule(pargs.start_lr_discriminator, pargs.lr_schedule_discriminator, d_opt, last_step=start_step) \
         if pargs.lr_schedule_discriminator else None
     trainer = GANTrainer(comm.DistributedModel(generator), comm.DistributedModel(discriminator), g_opt, d_opt, criterion_gan,
                          criterion_regression, loss_type_gan=pargs.loss_type_gan, loss_weight_gan=pargs.loss_weight_gan,
@@ -326,10 +333,9 @@ def main(pargs):
                          g_scheduler=g_sched, d_scheduler=d_sched,
                          update_frequency_generator=pargs.update_frequency_generator,
                          update_frequency_discriminator=pargs.update_frequency_discriminator)
-    if pargs.checkpoint:
-        trainer.load_checkpoint(pargs.checkpoint, comm, device)
+    trainer.step_count = start_step
     comm.printr('{:14.4f} REPORT: starting training'.format(dt.datetime.now().timestamp()), 0)
-    epoch, d_avg, g_avg = 0, 0., 0.
+    epoch, d_avg, g_avg = start_epoch, 0., 0.
     while trainer.step_count < pargs.max_steps:
         for batch in train_loader:
             inputs, outputs_real = batch[0], batch[1]
@@ -347,10 +353,13 @@ def main(pargs):
                 comm.printr('{:14.4f} REPORT validation: step {} d_loss {} g_loss {}'.format(
                     dt.datetime.now().timestamp(), trainer.step_count, vd, vg), 0)
             if pargs.save_frequency > 0 and trainer.step_count % pargs.save_frequency == 0 and comm.rank() == 0:
-                trainer.save_checkpoint(os.path.join(pargs.output_dir, "gan_step_{}.cpt".format(trainer.step_count)), epoch)
+                trainer.save_checkpoint(os.path.join(pargs.output_dir, pargs.model_prefix + "_step_" +
+                                                     str(trainer.step_count) + ".cpt"), epoch)     # train_gan.py:411
             if trainer.step_count >= pargs.max_steps:
                 break
         epoch += 1
+        if pargs.save_frequency > 0 and comm.rank() == 0:                                         # train_gan.py:419-431
+            trainer.save_checkpoint(os.path.join(pargs.output_dir, pargs.model_prefix + "_epoch_" + str(epoch) + ".cpt"), epoch)
     return trainer
 
 

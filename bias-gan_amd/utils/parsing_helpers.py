@@ -19,9 +19,28 @@ class FusedAdam(optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled))
-        self._m = {}
-        self._v = {}
+        self._mom = {}     # id(arena) -> (arena, exp_avg flat, exp_avg_sq flat): the arena reference keeps the key valid
         self._t = 0
+
+    def _moments(self, a):
+        """Flat first/second moment buffers over arena `a`.  If the parameters moved to a new arena since the moments
+        were created (module.to(), set_compute_dtype()), the values migrate parameter by parameter."""
+        ent = self._mom.get(id(a))
+        if ent is not None and ent[0] is a:
+            return ent[1], ent[2]
+        m, v = torch.zeros_like(a.master), torch.zeros_like(a.master)
+        for key, (old, om, ov) in list(self._mom.items()):
+            moved = False
+            for s_new in a.slots:
+                s_old = old.by_param.get(id(s_new.param))
+                if s_old is not None and s_old.param is s_new.param:
+                    a._view(m, s_new).copy_(old._view(om, s_old).to(m.device))
+                    a._view(v, s_new).copy_(old._view(ov, s_old).to(v.device))
+                    moved = True
+            if moved:
+                del self._mom[key]
+        self._mom[id(a)] = (a, m, v)
+        return m, v
 
     def _arenas(self):
         out = {}
@@ -50,10 +69,7 @@ class FusedAdam(optim.Optimizer):
         for a, g, slots in self._arenas():
             b1, b2 = g["betas"]
             bc1, bc2 = 1.0 - b1 ** self._t, 1.0 - b2 ** self._t
-            if id(a) not in self._m:
-                self._m[id(a)] = torch.zeros_like(a.master)
-                self._v[id(a)] = torch.zeros_like(a.master)
-            m, v = self._m[id(a)], self._v[id(a)]
+            m, v = self._moments(a)
             scale = 1.0
             ddp = getattr(a, "ddp", None)
             if ddp is not None:
@@ -69,15 +85,80 @@ class FusedAdam(optim.Optimizer):
             a.refresh_copies(cast=False)   # CRSK copies for the data-gradient GEMMs
             a._synced_version = a.master._version
 
+    # -- checkpoint interchange ----------------------------------------------------------------------
+    # The reference stores torch.optim.Adam.state_dict() under 'g_opt' / 'd_opt' (train_gan.py:401-411) and
+    # restores it with load_state_dict (comm/distributed.py:137-139):
+    #   {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{'lr', 'betas', 'eps', 'weight_decay',
+    #    'amsgrad', ..., 'params': [i, ...]}]},  i = position of the parameter in module.parameters().
+    # state_dict() emits exactly that (per-parameter tensors in the reference's [Cout,Cin,kh,kw] shapes, cut from the
+    # flat arena moments); load_state_dict() accepts it -- and the flat layout of this package's round-1 checkpoints.
     def state_dict(self):
-        sd = {"t": self._t, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
-        for i, (a, _, _) in enumerate(self._arenas_or_empty()):
-            if id(a) in self._m:
-                sd[f"exp_avg_{i}"] = self._m[id(a)].clone()
-                sd[f"exp_avg_sq_{i}"] = self._v[id(a)].clone()
-        return sd
+        groups, state, idx = [], {}, 0
+        have = bool(self._mom) and self._t > 0
+        for g in self.param_groups:
+            pg = {k: v for k, v in g.items() if k not in ("params", "decoupled")}
+            pg.setdefault("amsgrad", False)
+            pg.setdefault("maximize", False)
+            pg.setdefault("foreach", None)
+            pg.setdefault("capturable", False)
+            pg.setdefault("differentiable", False)
+            pg.setdefault("fused", None)
+            pg["params"] = list(range(idx, idx + len(g["params"])))
+            for p in g["params"]:
+                a = runtime.arena_of(p)
+                if have and a is not None and id(a) in self._mom and self._mom[id(a)][0] is a and p.requires_grad:
+                    _, m, v = self._mom[id(a)]
+                    sl = a.by_param[id(p)]
+                    state[idx] = {"step": torch.tensor(float(self._t)),
+                                  "exp_avg": a._view(m, sl).detach().clone().contiguous(),
+                                  "exp_avg_sq": a._view(v, sl).detach().clone().contiguous()}
+                idx += 1
+            groups.append(pg)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        if "state" not in sd:                      # flat layout of this package's earlier checkpoints
+            return self._load_flat(sd)
+        saved = sd["param_groups"]
+        if len(saved) != len(self.param_groups):
+            raise ValueError("FusedAdam.load_state_dict: the checkpoint has a different number of parameter groups")
+        order = []
+        for g, sg in zip(self.param_groups, saved):
+            if len(sg["params"]) != len(g["params"]):
+                raise ValueError("FusedAdam.load_state_dict: a parameter group's size does not match the checkpoint's")
+            for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+                if k in sg:
+                    g[k] = tuple(sg[k]) if k == "betas" else sg[k]
+            order += list(zip(sg["params"], g["params"]))
+        state = sd["state"]
+        if not state:
+            self._t = 0
+            self._mom = {}
+            return
+        steps = set()
+        for i, p in order:
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            a = runtime.arena_of(p)
+            if a is None:
+                raise RuntimeError("FusedAdam.load_state_dict: the parameter arenas do not exist yet; call module.arena() "
+                                   "(module on the GPU) before restoring optimiser moments")
+            m, v = self._moments(a)
+            sl = a.by_param[id(p)]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FusedAdam.load_state_dict: moment of parameter {i} has shape {tuple(st['exp_avg'].shape)}, "
+                                 f"the parameter {tuple(p.shape)}")
+            a._view(m, sl).copy_(st["exp_avg"].to(device=m.device, dtype=torch.float32))
+            a._view(v, sl).copy_(st["exp_avg_sq"].to(device=v.device, dtype=torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            # torch keeps one step count per parameter (a parameter without a gradient skips its update); the fused
+            # update has one bias correction for the whole arena
+            raise NotImplementedError(f"FusedAdam.load_state_dict: per-parameter step counts differ ({sorted(steps)})")
+        self._t = steps.pop() if steps else 0
+
+    def _load_flat(self, sd):
         self._t = sd["t"]
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
@@ -87,8 +168,7 @@ class FusedAdam(optim.Optimizer):
                                "(module on the GPU) before restoring optimiser moments")
         for i, (a, _, _) in enumerate(arenas):
             if f"exp_avg_{i}" in sd:
-                self._m[id(a)] = sd[f"exp_avg_{i}"].to(a.device).clone()
-                self._v[id(a)] = sd[f"exp_avg_sq_{i}"].to(a.device).clone()
+                self._mom[id(a)] = (a, sd[f"exp_avg_{i}"].to(a.device).clone(), sd[f"exp_avg_sq_{i}"].to(a.device).clone())
 
 
 def get_optimizer(parameters, optimizer_name, start_lr, adam_eps, weight_decay):
@@ -116,7 +196,8 @@ def get_lr_schedule(start_lr, scheduler_arg, optimizer, last_step=-1):
         gamma = float(scheduler_arg["decay_rate"])
         return optim.lr_scheduler.MultiStepLR(optimizer, milestones=milestones, gamma=gamma, last_epoch=init_step)
     elif scheduler_arg["type"] == "cosine_annealing":
-        return optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=scheduler_arg["t_max"],
-                                                    eta_min=scheduler_arg["eta_min"], last_epoch=init_step)
+        # the command line delivers strings (StoreDictKeyPair, train_gan.py:41-47)
+        return optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=int(scheduler_arg["t_max"]),
+                                                    eta_min=float(scheduler_arg["eta_min"]), last_epoch=init_step)
     else:
         raise ValueError("Error, scheduler type {} not supported.".format(scheduler_arg["type"]))

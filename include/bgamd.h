@@ -100,6 +100,10 @@ int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, f
 
 /* Reduction-dimension padding granule of the packed weight copies (elements). */
 int bg_conv_weight_kpad(int32_t dtype);
+/* Tuning / test hook for the forward and data-gradient GEMM launches of this process: -1 = tile family by the
+ * library's heuristics (default), 0 = the 64 x 64-per-wave tiles only, 2 = the fat-tile kernel (one 384/256-row tile
+ * per CU) wherever it is legal, small shapes included.  Results are the same up to summation order. */
+int bg_conv_set_variant(int32_t variant);
 /* Build the padded KRSC and CRSK copies for a batch of layers in one launch.  tbl
  * (device, n entries of 8 int64: src_off, krsc_off, crsk_off, K, RS, C, Cp, Kp in
  * elements; Cp/Kp = C/K rounded up to the granule) addresses each layer inside the

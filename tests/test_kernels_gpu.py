@@ -527,6 +527,104 @@ def test_conv_wide_tile_launch(dtype):
     assert_close(from_nhwc(yb2[:n], cout), F.conv2d(x2, wt), tol(dtype), "fwd, group 0")
 
 
+FAT_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, dil, groups
+    (2, 24, 20, 728, 728, 1, 1, 0, 1, 1),      # 384-row tiles, two channel tiles (the second partial), tiny pixel tiles
+    (2, 9, 7, 24, 136, 1, 1, 0, 1, 1),         # one-pixel tiles
+    (4, 16, 16, 40, 264, 1, 1, 0, 1, 2),       # statistic groups
+    (2, 11, 9, 128, 256, 1, 2, 0, 1, 1),       # strided 1x1 (the Block skip) and its lattice data gradient
+    (1, 16, 16, 304, 256, 3, 1, 1, 1, 1),      # 3x3: the tap-walking variant (256-row tiles)
+    (3, 5, 6, 520, 256, 3, 1, 2, 2, 1),        # dilated 3x3, mostly padding taps
+    (2, 21, 19, 72, 200, 3, 2, 1, 1, 1),       # strided 3x3 + strided data gradient
+    (6, 72, 48, 728, 728, 1, 1, 0, 1, 2),      # the workload's tile: 2 x 96 tiles of 216 pixels, two groups
+    (1, 150, 120, 64, 1032, 1, 1, 0, 1, 1),    # several rounds of 256-row tiles
+    (2, 130, 120, 24, 256, 3, 1, 1, 1, 1),     # 256 x 224 tiles with taps (one round against two of 256 x 112)
+    (2, 33, 31, 128, 128, 1, 1, 0, 1, 1),      # 128-row tiles (the configuration of activations beyond 2 GiB)
+    (2, 20, 18, 16, 128, 3, 1, 1, 1, 1),
+    (2, 21, 19, 24, 72, 3, 2, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", FAT_CASES)
+def test_conv_fat_tile_variant(case, dtype):
+    """The fat-tile GEMM kernel (one 384/256-row tile per CU, run-time pixel width) forced onto every legal launch:
+    forward with the statistics epilogue and the data gradient against torch, and against the classic tiles."""
+    n, h, w, cin, cout, k, s, p, d, groups = case
+    x = rnd((n, cin, h, w), 41, dtype)
+    wt = rnd((cout, cin, k, k), 42, dtype, 1.0 / math.sqrt(cin * k * k))
+    cinp, coutp = up(cin, dtype), up(cout, dtype)
+    ldx, ldy = cinp + 16, coutp + 8
+    desc, ho, wo = conv_desc(dtype, n, h, w, cin, cout, k, s, p, d, ldx, ldy)
+    xb, xv = to_nhwc(x, dtype, ldx, 8)
+    wpk, wpt = pack(krsc(wt, dtype), dtype)
+    go = rnd((n, cout, ho, wo), 44, dtype)
+    gb, gv = to_nhwc(go, dtype, ldy, 8)
+    ref = F.conv2d(x, wt, None, s, p, d)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, wt, None, s, p, d).backward(go)
+    outs = {}
+    try:
+        for variant in (2, 0):
+            L.conv_variant(variant)
+            yb = torch.full((n, ho, wo, ldy), 7.0, dtype=dtype, device=DEV)
+            yv = yb[..., 8:]
+            st = torch.zeros(2, groups, coutp, dtype=torch.float64, device=DEV)
+            L.call("bg_conv2d_fwd_stats", desc, xv.data_ptr(), wpk.data_ptr(), yv.data_ptr(), st[0].data_ptr(),
+                   st[1].data_ptr(), groups)
+            assert_close(from_nhwc(yv, cout), ref, tol(dtype), f"fwd (variant {variant})")
+            assert (yb[..., :8] == 7.0).all() and (yb[..., 8 + coutp:] == 7.0).all(), "wrote outside its channel slice"
+            if coutp > cout:
+                assert (yv[..., cout:coutp] == 0).all()
+            y = yv[..., :coutp].double()
+            per = n // groups
+            for g in range(groups):
+                yg = y[per * g:per * (g + 1)]
+                assert_close(st[0, g].cpu(), yg.sum((0, 1, 2)).cpu(), 1e-5, f"sum[{g}] (variant {variant})")
+                assert_close(st[1, g].cpu(), (yg * yg).sum((0, 1, 2)).cpu(), 1e-5, f"sumsq[{g}] (variant {variant})")
+            dxb = torch.full((n, h, w, ldx), 5.0, dtype=dtype, device=DEV)
+            dxv = dxb[..., 8:]
+            L.call("bg_conv2d_bwd_data", desc, gv.data_ptr(), wpt.data_ptr(), dxv.data_ptr())
+            assert_close(from_nhwc(dxv, cin), xr.grad, tol(dtype), f"bwd_data (variant {variant})")
+            assert (dxb[..., :8] == 5.0).all() and (dxb[..., 8 + cinp:] == 5.0).all()
+            outs[variant] = (yv.float().cpu(), dxv.float().cpu())
+    finally:
+        L.conv_variant(-1)
+    # same products, same fp32 accumulation per output element up to the order of the K-steps: the two tile families
+    # agree far inside the test tolerance
+    assert_close(outs[2][0][..., :cout], outs[0][0][..., :cout], 2e-6 if dtype == torch.float32 else 8e-3, "fat vs classic fwd")
+
+
+def test_conv_operands_beyond_2gib():
+    """Activations larger than 2 GiB (the 2304x1536x32 configuration's entry flow at batch 16): the fat-tile kernel rebases
+    its buffer descriptors per tile, so 32-bit offsets never span the tensor.  Sampled pixels (first, around the 2 GiB
+    boundary, last) against a matmul; statistics against the stored tensor."""
+    dtype = torch.bfloat16
+    n, h, w, c = 1, 2912, 2900, 128                      # 8.44 M pixels x 256 B = 2.16 GB per tensor
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((n, h, w, c), generator=g, device=DEV, dtype=torch.float32).to(dtype)
+    assert x.numel() * 2 > (1 << 31)
+    wt = rnd((c, c, 1, 1), 52, dtype, 1.0 / math.sqrt(c))
+    wpk, wpt = pack(krsc(wt, dtype), dtype)
+    y = torch.empty_like(x)
+    st = torch.zeros(2, 1, c, dtype=torch.float64, device=DEV)
+    desc = L.ConvDesc(L.BF16, n, h, w, c, h, w, c, 1, 1, 1, 0, 1, c, c)
+    L.call("bg_conv2d_fwd_stats", desc, x.data_ptr(), wpk.data_ptr(), y.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), 1)
+    m = h * w
+    rows = torch.tensor([0, 1, 4_194_303, 4_194_304, 4_194_305, 8_388_607, 8_388_608, 8_388_609, m - 2, m - 1], device=DEV)
+    xf, yf = x.view(m, c), y.view(m, c)
+    ref = xf[rows].float() @ wt.view(c, c).t().to(DEV)
+    assert_close(yf[rows].float().cpu(), ref.cpu(), 1e-2, "fwd rows")
+    ssum = torch.zeros(c, dtype=torch.float64, device=DEV)
+    for a in range(0, m, 1 << 20):
+        ssum += yf[a:a + (1 << 20)].double().sum(0)
+    assert_close(st[0, 0].cpu(), ssum.cpu(), 1e-5, "sum")
+    dx = torch.empty_like(x)
+    L.call("bg_conv2d_bwd_data", desc, y.data_ptr(), wpt.data_ptr(), dx.data_ptr())
+    ref2 = yf[rows].float() @ wt.view(c, c).to(DEV)
+    assert_close(dx.view(m, c)[rows].float().cpu(), ref2.cpu(), 1e-2, "bwd_data rows")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fwd_fused_statistics_per_group(dtype):
     """groups = 2: sums of the two halves of the batch land in separate rows."""

@@ -59,3 +59,34 @@ def test_dataset_on_device(tmp_path):
         assert a[0].is_cuda and a[3] == b[3]
         for u, v in zip(a[:3], b[:3]):
             np.testing.assert_allclose(u.cpu().numpy(), v.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_slot_reuse_with_large_samples(tmp_path):
+    """One ring slot, 64 MB samples, back-to-back get_sample() and a batch larger than the ring: the pinned host half of
+    a slot must not be overwritten by the next read while the H2D copy of the previous ticket still reads it
+    (bg_ring_release waits for that copy's event before the slot changes hands)."""
+    rng = np.random.default_rng(7)
+    nel = 16 * 1024 * 1024                      # 64 MB of float32 per sample
+    paths, arrs = [], []
+    for i in range(3):
+        a = rng.integers(0, 1 << 20, size=nel, dtype=np.int32).astype(np.float32)
+        p = str(tmp_path / f"big{i}.npy")
+        np.save(p, a.reshape(4, 2048, 2048))
+        paths.append(p)
+        arrs.append(a.reshape(4, 2048, 2048))
+    r = nr.numpy_reader(False, 0, ring_slots=1)
+    r.num_intra_threads = 4
+    r.parse(paths[0])
+    got = []
+    for rep in range(2):
+        for p in paths:                         # no host synchronisation between the reads
+            r.init_file(p)
+            got.append(r.get_sample(0))
+    torch.cuda.synchronize()
+    for k, t in enumerate(got):
+        assert torch.equal(t.cpu(), torch.from_numpy(arrs[k % 3])), f"sample {k} corrupted"
+    rb = nr.numpy_reader(True, 0, ring_slots=1)
+    rb.num_intra_threads = 4
+    rb.parse(paths[1]); rb.init_file(paths[1]); rb.set_batchsize(4)
+    b = rb.get_batch([3, 0, 2, 1])              # 4 x 16 MB through one slot
+    assert torch.equal(b.cpu(), torch.from_numpy(arrs[1][[3, 0, 2, 1]]))
