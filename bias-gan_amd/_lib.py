@@ -112,7 +112,7 @@ _SIGS = {
     "bg_pixel_loss_fwd": [c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
     "bg_pixel_loss_bwd": [c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
     "bg_gp_penalty": [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp],
-    "bg_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32,
+    "bg_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, C.c_double, C.c_double, c_f32, c_f32, c_i32, c_f32, c_f32,
                      c_f32, c_vp],
     "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
 }

@@ -1484,6 +1484,9 @@ int plan_fat(GemmConvParams& P, bool big) {   // big: an operand beyond the clas
     const int bk = 64 / (int)sizeof(T);
     const long long kt = (long long)P.KH * P.KW * ((P.CK + bk - 1) / bk);
     if (mode != 2 && !big && ((P.NO <= 128 && !fat128) || kt < 8 || P.M < 16384)) return 0;
+    // measured (scripts/bench_fat.py): the tap-walking variant on the decoder's 3x3 layers (hundreds of thousands of
+    // pixels, Cout 256) is 3-17 % behind the 256 x 256 classic tile; on the ASPP's few-pixel layers 13-15 % ahead
+    if (mode != 2 && !big && P.KH * P.KW > 1 && P.M >= 131072) return 0;
     const int groups = P.stat_group_pix ? (int)(P.M / P.stat_group_pix) : 1;
     const long long gp = P.M / groups;
     if (gp * groups != P.M || gp >= (1LL << 31)) return 0;

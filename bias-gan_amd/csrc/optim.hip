@@ -6,7 +6,7 @@ namespace {
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, bf16_t* __restrict__ p_lp, long long n, float lr, float b1, float b2,
-                            float eps, float wd, int decoupled, float bc1, float bc2, float gscale) {
+                            float omb1, float omb2, float eps, float wd, int decoupled, float bc1, float bc2, float gscale) {
     // torch.optim.Adam: g += wd*p; m = b1*m+(1-b1)g; v = b2*v+(1-b2)g^2;
     //                   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
     const float step = lr / bc1;
@@ -16,8 +16,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         float gv = g[i] * gscale;
         if (decoupled) pv *= (1.f - lr * wd);
         else gv = fmaf(wd, pv, gv);
-        const float mv = b1 * m[i] + (1.f - b1) * gv;
-        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        const float mv = b1 * m[i] + omb1 * gv;
+        const float vv = b2 * v[i] + omb2 * gv * gv;
         m[i] = mv;
         v[i] = vv;
         pv -= step * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
@@ -40,12 +40,13 @@ inline unsigned ew_grid(long long total) {
 
 }  // namespace
 
-extern "C" int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, int32_t decoupled, float bias_corr1,
+extern "C" int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, float lr, double beta1,
+                            double beta2, float eps, float weight_decay, int32_t decoupled, float bias_corr1,
                             float bias_corr2, float grad_scale, void* stream) {
     BG_CHECK_ARG(p && g && m && v && n > 0 && bias_corr1 > 0.f && bias_corr2 > 0.f, "bg_adam_step: bad args");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_lp,
-                       (long long)n, lr, beta1, beta2, eps, weight_decay, decoupled, bias_corr1, bias_corr2, grad_scale);
+                       (long long)n, lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay,
+                       decoupled, bias_corr1, bias_corr2, grad_scale);
     BG_CHECK_LAUNCH("adam_kernel");
     return BG_OK;
 }

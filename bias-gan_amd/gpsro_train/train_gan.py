@@ -315,16 +315,16 @@ def main(pargs):
     d_opt = ph.get_optimizer(discriminator.parameters(), pargs.optimizer_discriminator, pargs.start_lr_discriminator,
                              pargs.adam_eps, pargs.weight_decay)
     generator.train(), discriminator.train()
-    # The reference's order (train_gan.py:163-173): restore nets and optimisers FIRST, then build the schedules with
-    # last_step = the restored step -- the optimiser state carries the already decayed 'lr', and a schedule started at
-    # -1 would count the passed milestones (or the cosine phase) a second time.
+    # The reference's order (train_gan.py:163-173): restore nets and optimisers FIRST, then build the schedules at the
+    # restored step -- the optimiser state carries the already decayed 'lr', and a schedule started at -1 would count
+    # the passed milestones (or the cosine phase) a second time.
     start_step, start_epoch = 0, 0
     if pargs.checkpoint:
         generator.arena(), discriminator.arena()   # the optimiser moments are flat buffers over the parameter arenas
         start_step, start_epoch = comm.init_gan_training_state(generator, discriminator, g_opt, d_opt, pargs.checkpoint, device)
-    g_sched = ph.get_lr_schedule(pargs.start_lr_generator, pargs.lr_schedule_generator, g_opt, last_step=start_step) \
+    g_sched = ph.resume_lr_schedule(pargs.start_lr_generator, pargs.lr_schedule_generator, g_opt, start_step) \
         if pargs.lr_schedule_generator else None
-    d_sched = ph.get_lr_schedule(pargs.start_lr_discriminator, pargs.lr_schedule_discriminator, d_opt, last_step=start_step) \
+    d_sched = ph.resume_lr_schedule(pargs.start_lr_discriminator, pargs.lr_schedule_discriminator, d_opt, start_step) \
         if pargs.lr_schedule_discriminator else None
     trainer = GANTrainer(comm.DistributedModel(generator), comm.DistributedModel(discriminator), g_opt, d_opt, criterion_gan,
                          criterion_regression, loss_type_gan=pargs.loss_type_gan, loss_weight_gan=pargs.loss_weight_gan,

@@ -103,6 +103,7 @@ class FusedAdam(optim.Optimizer):
             pg.setdefault("capturable", False)
             pg.setdefault("differentiable", False)
             pg.setdefault("fused", None)
+            pg.setdefault("decoupled_weight_decay", bool(g.get("decoupled", False)))   # torch >= 2.7 keeps Adam/AdamW apart by this
             pg["params"] = list(range(idx, idx + len(g["params"])))
             for p in g["params"]:
                 a = runtime.arena_of(p)
@@ -201,3 +202,23 @@ def get_lr_schedule(start_lr, scheduler_arg, optimizer, last_step=-1):
                                                     eta_min=float(scheduler_arg["eta_min"]), last_epoch=init_step)
     else:
         raise ValueError("Error, scheduler type {} not supported.".format(scheduler_arg["type"]))
+
+
+def resume_lr_schedule(start_lr, scheduler_arg, optimizer, start_step):
+    """Schedule for a run restored at `start_step`, continuing exactly where the saved run stopped.
+
+    The reference builds it as get_lr_schedule(..., last_step=start_step) (train_gan.py:170-173); torch's scheduler
+    constructor then performs one step of its own, so the reference's resumed run is one scheduler step AHEAD of the
+    run that wrote the checkpoint (a milestone at start_step + 1 fires before the first resumed update).  Here the
+    schedule is built from step 0 and moved to `start_step` with its closed form: same LR at every step as an
+    uninterrupted run."""
+    for g in optimizer.param_groups:
+        g["lr"] = g.get("initial_lr", start_lr)
+    sched = get_lr_schedule(start_lr, scheduler_arg, optimizer, last_step=-1)
+    if start_step > 0:
+        sched.last_epoch = int(start_step)
+        sched._step_count = int(start_step) + 1
+        for g, lr in zip(optimizer.param_groups, sched._get_closed_form_lr()):
+            g["lr"] = lr
+        sched._last_lr = [g["lr"] for g in optimizer.param_groups]
+    return sched

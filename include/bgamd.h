@@ -350,8 +350,10 @@ int bg_gp_penalty(const float* g, int32_t N, int32_t C, int32_t HW, float inv_no
  * utils/parsing_helpers.py:8-12) with the low-precision weight copy fused in.
  * g is multiplied by grad_scale first (1/world_size after a SUM all-reduce).
  * ------------------------------------------------------------------------- */
+/* beta1 / beta2 are doubles: torch evaluates 1 - beta in double before rounding it to the tensors' fp32 (0.001f, not
+ * 1.f - 0.999f, which is 1.3e-5 off), and checkpoints interchange the moments. */
 int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf16 copy or NULL */, int64_t n, float lr,
-                 float beta1, float beta2, float eps, float weight_decay, int32_t decoupled, float bias_corr1,
+                 double beta1, double beta2, float eps, float weight_decay, int32_t decoupled, float bias_corr1,
                  float bias_corr2, float grad_scale, void* stream);
 int bg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 

@@ -119,6 +119,85 @@ def golden_generator(tag, c, h, w, n, seed, upsampler="Interpolate", grad_full=N
     print("generator", tag, "loss", loss.item())
 
 
+def golden_generator_noise(tag, c, nd, h, w, n, seed, noise_type="Uniform", noise_seed=77):
+    """Generator with noise_dimensions > 0 -- the reference's default (train_gan.py:460): the noise is drawn on the HOST
+    RNG stream by torch.distributions...rsample inside forward (deeplab_gan.py:85-90), so it is a function of
+    torch.manual_seed alone.  Stored: the draw itself (pins draw order / shape), output, gradient checksums."""
+    g = ref_gan.Generator(c, c, "Interpolate", noise_type, nd, os=16, pretrained=False, normalizer=nn.BatchNorm2d)
+    spec = orc.generator_spec(c, c, nd, "batch")
+    sd = g.state_dict()
+    assert [k for k, _, _ in spec] == list(sd.keys())
+    g.load_state_dict(orc.fill_state(spec, seed))
+    g.train()
+    x, y = orc.synthetic_fields(n, c, h, w, seed + 100)
+    torch.manual_seed(noise_seed)
+    noise = g.dist.rsample((n, nd, h, w))
+    torch.manual_seed(noise_seed)
+    out = g(x)
+    loss = (out - y).abs().mean()
+    loss.backward()
+    res = {"out": out.detach().numpy(), "loss": np.array(loss.item()), "noise": noise.numpy()}
+    cs = checksums((k, p.grad) for k, p in g.named_parameters())
+    res["grad_keys"] = np.array(list(cs.keys()))
+    res["grad_cs"] = np.stack(list(cs.values()))
+    res["grad::model.xception_features.conv1.weight"] = dict(g.named_parameters())["model.xception_features.conv1.weight"].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"generator_{tag}.npz"), meta=json.dumps(
+        dict(c=c, nd=nd, h=h, w=w, n=n, seed=seed, field_seed=seed + 100, noise_type=noise_type, noise_seed=noise_seed)), **res)
+    print("generator", tag, "loss", loss.item())
+
+
+def golden_checkpoint_structure(c=4, h=64, w=64, n=2, seed=21):
+    """What the reference puts into a .cpt (train_gan.py:401-411): one real loop iteration of the reference modules
+    under torch.optim.Adam, then the STRUCTURE of the checkpoint dictionary -- keys in order, shapes, dtypes, the
+    optimiser's param_groups, per-parameter step counts -- plus three checksums per tensor.  (The tensors themselves
+    are 1.1 GB; the structure and the sums are what a loader has to agree with.)"""
+    g, gspec = build_ref_generator(c, nn.BatchNorm2d, seed)
+    d, dspec = build_ref_discriminator(c, h, w, nn.BatchNorm2d, seed + 1)
+    g.train(), d.train()
+    g_opt = torch.optim.Adam(g.parameters(), lr=1e-4, eps=1e-8, weight_decay=1e-5)
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, eps=1e-8, weight_decay=1e-5)
+    g_opt.param_groups[0]["initial_lr"] = 1e-4          # utils/parsing_helpers.py:19
+    d_opt.param_groups[0]["initial_lr"] = 1e-4
+    crit = ref_losses.GANLoss("ModifiedMinMax", n, torch.device("cpu"))
+    x, y = orc.synthetic_fields(n, c, h, w, 1000)
+    torch.manual_seed(seed)
+    fake = g(x)                                           # train_gan.py:250-271
+    lr_, _ = d(y)
+    lf_, _ = d(fake)
+    d_loss = crit.d_loss(lr_, lf_)
+    d_opt.zero_grad()
+    d_loss.backward()
+    d_opt.step()
+    fake = g(x)                                           # train_gan.py:273-298
+    lf_, _ = d(fake)
+    g_loss = crit.g_loss(lf_) + (fake - y).abs().mean()
+    g_opt.zero_grad()
+    g_loss.backward()
+    g_opt.step()
+    ck = {"step": 1, "epoch": 0, "generator": g.state_dict(), "discriminator": d.state_dict(),
+          "g_opt": g_opt.state_dict(), "d_opt": d_opt.state_dict(), "amp": None}
+
+    def tens(t):
+        t64 = t.detach().double()
+        return {"shape": list(t.shape), "dtype": str(t.dtype).replace("torch.", ""),
+                "cs": [t64.sum().item(), t64.abs().sum().item(), (t64 * t64).sum().item()]}
+
+    def opt(sd):
+        return {"param_groups": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in pg.items()} for pg in sd["param_groups"]],
+                "state": {str(i): {"step": float(st["step"]), "step_is_tensor": torch.is_tensor(st["step"]),
+                                   "exp_avg": tens(st["exp_avg"]), "exp_avg_sq": tens(st["exp_avg_sq"])}
+                          for i, st in sd["state"].items()}}
+    out = {"keys": list(ck.keys()), "step": ck["step"], "epoch": ck["epoch"],
+           "generator": [[k, tens(v)] for k, v in ck["generator"].items()],
+           "discriminator": [[k, tens(v)] for k, v in ck["discriminator"].items()],
+           "g_opt": opt(ck["g_opt"]), "d_opt": opt(ck["d_opt"]),
+           "meta": dict(c=c, h=h, w=w, n=n, seed=seed, field_seed=1000, lr=1e-4, eps=1e-8, weight_decay=1e-5,
+                        d_loss=d_loss.item(), g_loss=g_loss.item())}
+    with open(os.path.join(HERE, "checkpoint_structure.json"), "w") as f:
+        json.dump(out, f)
+    print("checkpoint structure: d_loss", d_loss.item(), "g_loss", g_loss.item())
+
+
 def golden_discriminator(tag, c, h, w, n, seed, norm_cls):
     d, spec = build_ref_discriminator(c, h, w, norm_cls, seed)
     d.train()
@@ -667,6 +746,11 @@ if __name__ == "__main__":
     if "all" in which or "gen" in which:
         golden_generator("c4_64x64", 4, 64, 64, 2, seed=1)
         golden_generator("c8_40x56", 8, 40, 56, 2, seed=2)
+    if "all" in which or "gen_noise" in which:
+        golden_generator_noise("nd1_c4_40x56", 4, 1, 40, 56, 2, seed=8)
+        golden_generator_noise("nd2n_c4_40x56", 4, 2, 40, 56, 2, seed=9, noise_type="Normal")
+    if "all" in which or "cpt" in which:
+        golden_checkpoint_structure()
     if "all" in which or "deconv" in which:
         # the Deconv upsamplers only exist on H = 16a-13, W = 16b-11 grids (19x37 is the GPS-RO grid)
         golden_generator("deconv_c4_19x37", 4, 19, 37, 2, seed=6, upsampler="Deconv",

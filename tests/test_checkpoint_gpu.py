@@ -68,7 +68,7 @@ def test_optimizer_state_is_torch_adam_layout(name):
         opt.step()
         ref.step()
     for p, q in zip(net.parameters(), ps):
-        assert torch.allclose(p.detach().cpu(), q.detach(), rtol=2e-6, atol=1e-7)
+        assert torch.allclose(p.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
     ours, theirs = opt.state_dict(), ref.state_dict()
     # structure: the same keys, parameter indices and step counts
     assert set(ours.keys()) == {"state", "param_groups"}
@@ -81,8 +81,8 @@ def test_optimizer_state_is_torch_adam_layout(name):
         assert set(a.keys()) == set(b.keys()) == {"step", "exp_avg", "exp_avg_sq"}
         assert float(a["step"]) == float(b["step"]) == 2.0
         assert a["exp_avg"].shape == b["exp_avg"].shape == ps[i].shape and a["exp_avg"].is_contiguous()
-        assert torch.allclose(a["exp_avg"].cpu(), b["exp_avg"], rtol=1e-5, atol=1e-9)
-        assert torch.allclose(a["exp_avg_sq"].cpu(), b["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+        assert torch.allclose(a["exp_avg"].cpu(), b["exp_avg"], rtol=2e-6, atol=1e-10)
+        assert torch.allclose(a["exp_avg_sq"].cpu(), b["exp_avg_sq"], rtol=2e-6, atol=1e-14)
 
     # (1) torch's state into a FRESH FusedAdam (the reference's .cpt read by this package) ...
     net2 = _Net().to(DEV)
@@ -106,9 +106,9 @@ def test_optimizer_state_is_torch_adam_layout(name):
         q.grad, q3.grad = g.clone(), g.clone()
     opt.step(), opt2.step(), ref.step(), ref3.step()
     for p, p2, q, q3 in zip(net.parameters(), net2.parameters(), ps, ps3):
-        assert torch.allclose(p.detach().cpu(), q.detach(), rtol=2e-6, atol=1e-7)
-        assert torch.allclose(p2.detach().cpu(), q.detach(), rtol=2e-6, atol=1e-7)
-        assert torch.allclose(q3.detach(), q.detach(), rtol=2e-6, atol=1e-7)
+        assert torch.allclose(p.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(p2.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(q3.detach(), q.detach(), rtol=1e-5, atol=1e-6)
     # the moments follow the parameters into a rebuilt arena (module.to() / set_compute_dtype())
     before = opt.state_dict()
     net.set_compute_dtype(torch.bfloat16)

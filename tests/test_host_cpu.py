@@ -169,3 +169,29 @@ def test_world_size_2_gloo():
         assert fsum == float(np.arange(1000).sum() * 3)
         assert f2 == [3.0] * 7
         assert t == [0.0, 0.0, 0.0]
+
+
+def test_resume_lr_schedule_continues_exactly():
+    """parsing_helpers.resume_lr_schedule: a schedule restored at step s gives the LRs of an uninterrupted run from s on
+    (multistep with a milestone right at / after the restore point, cosine annealing)."""
+    import torch
+    from bias_gan_amd.utils import parsing_helpers as ph
+    for arg in ({"type": "multistep", "milestones": "2 4", "decay_rate": "0.5"},
+                {"type": "cosine_annealing", "t_max": "8", "eta_min": "0.0"}):
+        p = [torch.nn.Parameter(torch.zeros(3))]
+        o = torch.optim.Adam(p, lr=1e-3)
+        o.param_groups[0]["initial_lr"] = 1e-3
+        s = ph.get_lr_schedule(1e-3, arg, o)
+        lrs = []
+        for _ in range(8):
+            lrs.append(o.param_groups[0]["lr"])
+            o.step()
+            s.step()
+        for start in (1, 3, 4, 5):
+            o2 = torch.optim.Adam(p, lr=lrs[start])          # what the checkpoint's optimiser state carries
+            o2.param_groups[0]["initial_lr"] = 1e-3
+            s2 = ph.resume_lr_schedule(1e-3, arg, o2, start)
+            for k in range(start, 8):
+                assert abs(o2.param_groups[0]["lr"] - lrs[k]) < 1e-12, (arg["type"], start, k)
+                o2.step()
+                s2.step()

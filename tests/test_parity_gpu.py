@@ -174,6 +174,100 @@ def test_generator_vs_reference_golden(golden_dir, tag, dtype):
     assert rms_err(oe.cpu(), z["out_eval"]) <= (5e-4 if dtype == F32 else 3e-1)
 
 
+@pytest.mark.parametrize("tag", ["nd1_c4_40x56", "nd2n_c4_40x56"])
+def test_generator_with_noise_vs_reference_golden(golden_dir, tag):
+    """noise_dimensions > 0 -- the reference's default (train_gan.py:460): the noise comes off the HOST RNG stream
+    inside forward (deeplab_gan.py:85-90).  Same seed -> the same draw bit for bit, the same output; an injected noise
+    tensor gives the same result."""
+    z, m = gz(golden_dir, f"generator_{tag}.npz")
+    c, nd = m["c"], m["nd"]
+    spec = orc.generator_spec(c, c, nd, "batch")
+    G = dxg.Generator(c, c, "Interpolate", m["noise_type"], nd, normalizer=nn.BatchNorm2d, compute_dtype=F32)
+    G.load_state_dict(orc.fill_state(spec, m["seed"]))
+    G.to(DEV).train()
+    x, y = orc.synthetic_fields(m["n"], c, m["h"], m["w"], m["field_seed"])
+    torch.manual_seed(m["noise_seed"])
+    np.testing.assert_array_equal(G.dist.rsample((m["n"], nd, m["h"], m["w"])).numpy(), z["noise"])   # bit-exact host draw
+    torch.manual_seed(m["noise_seed"])
+    out = G(x.to(DEV))
+    e = rel_err(out.detach().cpu(), z["out"])
+    print(f"generator {tag}: fwd vs reference max-rel {e:.2e}")
+    assert e <= 2e-4
+    loss = losses.L1Loss()(out, y.to(DEV))
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    loss.backward()
+    named = dict(G.named_parameters())
+    k0 = "model.xception_features.conv1.weight"     # the layer that sees the noise channels
+    assert named[k0].shape[1] == c + nd
+    assert rms_err(named[k0].grad.cpu(), z["grad::" + k0]) <= 3e-2
+    ref = dict(zip([str(k) for k in z["grad_keys"]], z["grad_cs"]))
+    for k, p in named.items():
+        assert abs(cs(p.grad)[2] - ref[k][2]) <= 6e-2 * ref[k][2] + 1e-12, k
+    G2 = dxg.Generator(c, c, "Interpolate", m["noise_type"], nd, normalizer=nn.BatchNorm2d, compute_dtype=F32)
+    G2.load_state_dict(orc.fill_state(spec, m["seed"]))
+    G2.to(DEV).train()
+    out2 = G2(x.to(DEV), noise=torch.from_numpy(z["noise"]).to(DEV))
+    assert torch.equal(out2, out.detach())
+
+
+def test_checkpoint_matches_reference_structure(tmp_path, golden_dir):
+    """The .cpt this package writes after one loop iteration against the STRUCTURE of the one the reference writes after
+    the same iteration (tests/golden/checkpoint_structure.json, from the reference's modules + torch.optim.Adam):
+    dictionary keys, state_dict keys in order, shapes, dtypes, optimiser param_groups, parameter indices, step counts;
+    tensor checksums within the one-iteration tolerances (weights moved by one sign-like Adam step of 1e-4)."""
+    ref = json.load(open(os.path.join(golden_dir, "checkpoint_structure.json")))
+    m = ref["meta"]
+    c, h, w, n = m["c"], m["h"], m["w"], m["n"]
+    G, _ = build_generator(c, m["seed"], F32)
+    D, _ = build_discriminator(c, h, w, m["seed"] + 1, F32)
+    G.train(), D.train()
+    crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+    tr = GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", m["lr"], m["eps"], m["weight_decay"]),
+                    ph.get_optimizer(D.parameters(), "Adam", m["lr"], m["eps"], m["weight_decay"]), crit, losses.L1Loss())
+    x, y = orc.synthetic_fields(n, c, h, w, m["field_seed"])
+    torch.manual_seed(m["seed"])
+    d_loss, g_loss = tr.step(x.to(DEV), y.to(DEV))
+    assert abs(d_loss.item() - m["d_loss"]) <= 1e-3 * abs(m["d_loss"]) and abs(g_loss.item() - m["g_loss"]) <= 2e-2 * abs(m["g_loss"])
+    path = str(tmp_path / "model_step_1.cpt")
+    tr.save_checkpoint(path, epoch=0)
+    ck = torch.load(path, map_location="cpu")
+    assert list(ck.keys()) == ref["keys"] and ck["step"] == 1 and ck["epoch"] == 0
+    for net in ("generator", "discriminator"):
+        assert [k for k, _ in ref[net]] == list(ck[net].keys()), net
+        for k, t in ref[net]:
+            v = ck[net][k]
+            assert list(v.shape) == t["shape"] and str(v.dtype).replace("torch.", "") == t["dtype"], (net, k)
+            got = cs(v)
+            assert abs(got[1] - t["cs"][1]) <= 2e-4 * t["cs"][1] + 4e-4 * max(1, v.numel() ** 0.5), (net, k, got, t["cs"])
+    for name in ("g_opt", "d_opt"):
+        o, r = ck[name], ref[name]
+        assert set(o.keys()) == {"state", "param_groups"} and len(o["param_groups"]) == len(r["param_groups"]) == 1
+        og, rg = o["param_groups"][0], r["param_groups"][0]
+        assert og["params"] == rg["params"]
+        for k in ("lr", "eps", "weight_decay", "amsgrad", "initial_lr"):
+            assert og[k] == rg[k], (name, k)
+        assert list(og["betas"]) == list(rg["betas"])
+        assert set(rg.keys()) <= set(og.keys()), set(rg.keys()) - set(og.keys())      # torch.optim.Adam reads all of its own keys
+        assert [str(i) for i in o["state"].keys()] == list(r["state"].keys())
+        worst = 0.0
+        for i, st in o["state"].items():
+            rs = r["state"][str(i)]
+            assert float(st["step"]) == rs["step"] == 1.0 and torch.is_tensor(st["step"]) == rs["step_is_tensor"]
+            for kk in ("exp_avg", "exp_avg_sq"):
+                assert list(st[kk].shape) == rs[kk]["shape"] and str(st[kk].dtype) == "torch.float32"
+            # first moment = 0.1 * gradient.  D's gradients are taken at the initial weights: the gradient tolerance of
+            # the module tests (sum of squares 6e-2).  G's come through D AFTER D's first, sign-like Adam step, which
+            # turns rounding noise into +-1e-4 per weight (the reason g_loss is only pinned to 2e-2): 3e-1
+            got, want = cs(st["exp_avg"])[2], rs["exp_avg"]["cs"][2]
+            worst = max(worst, abs(got - want) / (want + 1e-30))
+            assert abs(got - want) <= (6e-2 if name == "d_opt" else 3e-1) * want + 1e-20, (name, i, got, want)
+        print(f"{name}: worst first-moment sum-of-squares deviation {worst:.2e}")
+    # and the reference's own optimiser class accepts it
+    shapes = [t["shape"] for _, t in ref["generator"] if True]
+    ps = [nn.Parameter(torch.zeros(p.shape)) for p in G.parameters()]
+    torch.optim.Adam(ps, lr=1.0).load_state_dict(ck["g_opt"])
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("tag", ["c4_64x64_bn", "c8_40x56_bn", "c4_64x64_in"])
 def test_discriminator_vs_reference_golden(golden_dir, tag, dtype):
