@@ -37,9 +37,17 @@ import torch.nn as nn  # noqa: E402
 
 # forward GMAC per sample at 1152x768x16 (G 313.9, D 190.2);
 # a step needs 4 G-units + 8 D-units  ->  2776.9 GMAC = 5.5538 TFLOP per sample.
-W_ALG_TFLOP = {(1152, 768, 16): 2.0 * (4 * 313.9 + 8 * 190.2) * 1e-3,
-               (256, 256, 16): 2.0 * (4 * 23.25 + 8 * 14.09) * 1e-3,
-               (64, 64, 4): 2.0 * (4 * 1.439 + 8 * 0.866) * 1e-3}
+FWD_GMAC = {(1152, 768, 16): (313.9, 190.2), (256, 256, 16): (23.25, 14.09), (64, 64, 4): (1.439, 0.866),
+            (2304, 1536, 32): (1272.9, 776.9)}
+
+
+def w_alg_tflop(h, w, c, loss):
+    """4 G-units + 8 D-units per sample and step; the gradient penalty adds one D forward and one data-gradient-only D
+    backward = 2 D-units (c4 = c3 + 2 D = 6.31 TFLOP)."""
+    if (h, w, c) not in FWD_GMAC:
+        return None
+    g, d = FWD_GMAC[(h, w, c)]
+    return 2.0 * (4 * g + (10 if loss == "wgan-gp" else 8) * d) * 1e-3
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -53,7 +61,11 @@ def parse():
     ap.add_argument("--channels", type=int, default=16)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--loss", default="mmm", choices=["mmm", "wgan-gp"],
+                    help="mmm: ModifiedMinMax + L1 (configs[2], the headline); wgan-gp: Wasserstein + gradient penalty "
+                         "(configs[3]: one more D forward and a data-gradient-only D backward per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-floor", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write (entry, flops, bytes, ms) of every launch of the profile step")
     return ap.parse_args()
@@ -99,6 +111,43 @@ def cpu_baseline(c, h, w):
                       f"{dt:.1f} s"}
 
 
+def host_floor(c, n, dtype, device, mode):
+    """Host time to enqueue one step, measured where the device cannot push back: the same nets, batch and launch
+    sequence on 64x64 fields (the GPU work per launch is a few microseconds, the Python / ctypes / autograd work per
+    launch is what it is at full size).  hipGraph replay of the no-grad generator forward is switched off so that the
+    count of launches matches the full-size step."""
+    import contextlib
+    import torch.nn as nn
+    from bias_gan_amd.architecture.gpsro import deeplab_gan as dxg
+    from bias_gan_amd.gpsro_train.train_gan import GANTrainer
+    from bias_gan_amd.utils import losses
+    from bias_gan_amd.utils import parsing_helpers as ph
+    from bias_gan_amd import graphs
+    old, graphs._MODE = graphs._MODE, "0"
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, os=16, pretrained=False, normalizer=nn.BatchNorm2d,
+                              compute_dtype=dtype).to(device)
+            D = dxg.Discriminator(n_input=c, os=16, pretrained=False, normalizer=nn.BatchNorm2d, input_size=(64, 64),
+                                  compute_dtype=dtype).to(device)
+        G.train(), D.train()
+        tr = GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5),
+                        ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5), losses.GANLoss(mode, n, device),
+                        losses.L1Loss(), loss_type_gan=mode, loss_weight_gp=10.0)
+        x, y = synthetic_batch(n, c, 64, 64, 1, device)
+        for _ in range(3):
+            tr.step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.step(x, y)
+        dt = (time.perf_counter() - t0) / 5
+        torch.cuda.synchronize()
+        return 1e3 * dt
+    finally:
+        graphs._MODE = old
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,8 +191,15 @@ def main():
     g_opt = ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5)
     d_opt = ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5)
     Gd, Dd = comm.DistributedModel(G), comm.DistributedModel(D)
-    crit = losses.GANLoss("ModifiedMinMax", n, device)
-    trainer = GANTrainer(Gd, Dd, g_opt, d_opt, crit, losses.L1Loss())
+    mode = "Wasserstein" if args.loss == "wgan-gp" else "ModifiedMinMax"
+    crit = losses.GANLoss(mode, n, device)
+    trainer = GANTrainer(Gd, Dd, g_opt, d_opt, crit, losses.L1Loss(), loss_type_gan=mode, loss_weight_gp=10.0)
+    if world > 1:   # what actually carries the gradients: the driver's torchrun line must show RCCL with N ranks
+        devs = [None] * world
+        dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} ({torch.cuda.get_device_name()})")
+        if rank == 0:
+            print(f"[bench] torch.distributed backend {dist.get_backend()} (RCCL on ROCm), world size {dist.get_world_size()}: "
+                  + "; ".join(devs), file=sys.stderr, flush=True)
 
     batches = [synthetic_batch(n, c, h, w, seed + 1000 * i, device) for i in range(2)]
 
@@ -161,12 +217,17 @@ def main():
         trainer.step(*batches[i % 2])
     sync_all()
     note(f"timing {args.steps} steps")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step durations (no host sync)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         d_loss, g_loss = trainer.step(*batches[i % 2])
+        marks[i + 1].record()
     host_enqueue = time.perf_counter() - t0      # host time to ENQUEUE the steps (no device sync in the loop)
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     note(f"host enqueue {1e3 * host_enqueue / args.steps:.1f} ms/step")
     note(f"done: {1e3 * elapsed / args.steps:.1f} ms/step")
     if world > 1:
@@ -181,12 +242,15 @@ def main():
         "metric": "climate-field samples/sec (G+D step) at 1152x768x16" if (h, w, c) == (1152, 768, 16)
         else f"climate-field samples/sec (G+D step) at {h}x{w}x{c}",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": median_ms,   # median of per-step device times (HIP events)
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{h}x{w}x{c} synthetic fields, batch {n}/GPU, DeepLabv3+/Xception-65 generator "
                                "(Interpolate upsampler, noise_dimensions 0) + Xception-65/Linear discriminator, "
-                               "BatchNorm, ModifiedMinMax + L1, Adam(1e-4, eps 1e-8, wd 1e-5), D-step + G-step per step",
-                   "global_batch": n * world, "parallelism": f"dp{world}", "last_d_loss": d_loss, "last_g_loss": g_loss},
+                               "BatchNorm, " + ("Wasserstein + gradient penalty (weight 10) + L1" if args.loss == "wgan-gp" else "ModifiedMinMax + L1")
+                               + ", Adam(1e-4, eps 1e-8, wd 1e-5), D-step + G-step per step",
+                   "global_batch": n * world, "parallelism": f"dp{world}", "last_d_loss": d_loss, "last_g_loss": g_loss,
+                   "collective_backend": (dist.get_backend() if world > 1 else None)},
     }
 
     # ---- roofline: one extra (un-timed) step with HIP events around every C-ABI launch
@@ -227,10 +291,12 @@ def main():
             traffic = None
         cnt, secs, flops, _ = mfma[dom]
         achieved = flops / secs * 1e-12
-        walg = W_ALG_TFLOP.get((h, w, c))
+        walg = w_alg_tflop(h, w, c, args.loss)
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": traffic,
+            "traffic_source": None if traffic is None else "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "command (profiles/*_pmc_hbm_traffic.json); not re-measured in this run",
             "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt, "alg_gflop_per_launch": flops / cnt * 1e-9,
             "step_conv_stack_tflops": None if walg is None else value / world * walg,
             "step_conv_stack_frac": None if walg is None else value / world * walg / PEAK_BF16_TFLOPS,
@@ -239,6 +305,8 @@ def main():
                              "alg_gbps": (v[3] / v[1] * 1e-9 if v[1] > 0 else 0.0)}
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
         }
+    if rank == 0 and world == 1 and not args.no_host_floor:
+        out["host_ms_per_step"] = host_floor(c, n, dtype, device, mode)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(c, h, w)
     if world > 1:

@@ -54,6 +54,7 @@ _SIGS = {
     "bg_conv2d_fwd_stats": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "bg_conv2d_bwd_data": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bg_conv2d_bwd_weight_grouped": [c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_pack_conv_weights": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
     "bg_dwconv3x3_fwd": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_data": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
@@ -114,6 +115,8 @@ _SIGS = {
     "bg_gp_penalty": [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp],
     "bg_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, C.c_double, C.c_double, c_f32, c_f32, c_i32, c_f32, c_f32,
                      c_f32, c_vp],
+    "bg_set_floats": [c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp],
+    "bg_adam_step_dev": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, C.c_double, C.c_double, c_f32, c_f32, c_i32, c_vp],
     "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
 }
 EXPORTS = sorted(list(_SIGS) + list(_HOST_SIGS) + ["bg_last_error", "bg_conv_weight_kpad", "bg_conv_set_variant"])
@@ -223,7 +226,7 @@ def _alg_bytes(name, a) -> float:
         return float(a[3]) * a[5] * (4 * a[4] + _es(a[0]) * a[6])
     if name == "bg_nhwc_to_nchw":
         return float(a[4]) * a[6] * a[5] * (4 + _es(a[0]))
-    if name == "bg_adam_step":
+    if name in ("bg_adam_step", "bg_adam_step_dev"):
         return float(a[5]) * (7 * 4 + (2 if a[4] is not None else 0))
     if name == "bg_resize_bilinear_fwd":
         return float(a[6]) * a[11] * (a[7] * a[8] * _es(a[0]) + a[9] * a[10] * _es(a[1]))
@@ -271,7 +274,10 @@ def call(name, *args):
         e0.record()
         rc = fn(*args, stream())
         e1.record()
-        flops = _conv_flops(args[0]) if name.startswith("bg_conv2d") else 0.0
+        if name == "bg_conv2d_bwd_weight_grouped":
+            flops = 2.0 * args[2] * args[3] * args[4] * args[5]
+        else:
+            flops = _conv_flops(args[0]) if name.startswith("bg_conv2d") else 0.0
         PROFILE.append((name, flops, e0, e1, _alg_bytes(name, args)))
     else:
         rc = fn(*args, stream())

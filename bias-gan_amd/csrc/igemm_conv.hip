@@ -1393,6 +1393,188 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
         }
 }
 
+// ------------------------------------------------- gang weight gradient ----
+// Weight gradient of L pointwise convolutions of ONE shape (the 48 + 2 identical 728 -> 728 layers of the middle flow;
+// any single 1x1 layer is the L = 1 case) as one launch, issued when the backward pass has produced all their
+// gradients: dW_l[co][ci] += sum_p dy_l[p][co] * x_l[p][ci].  The reduction runs over pixels -- the slow dimension of both
+// operands -- and the output is tiny (9 tiles of 256 x 256 for 728 x 728), so a single layer can only fill the chip by
+// splitting its pixels over many workgroups that all add a whole copy of dW with float atomics (the per-layer kernel
+// above: 14 splits, a third of its time in atomics, operands re-streamed per split).  Here the (layer, pixel) space of
+// the whole group is cut into `gangs` equal ranges; gang g = the T workgroups of the T output tiles walk range g
+// together (the T tiles read the same dy / x rows at the same time: one trip to HBM, the rest from L2 / Infinity
+// Cache), each keeps its 256 x 256 tile in registers across a layer's pixels and adds it to dW_l when the layer (or the
+// range) ends: with ranges at least one layer long every dW tile receives at most two adds -- fp32 addition commutes, so
+// the result does not depend on their order: deterministic.  Staging: 32-pixel K-steps, both operands global -> LDS by
+// DMA (a 1-KiB piece = 2 pixel rows x 256 channels) into a 4-stage ring, pieces issued between the MFMA groups;
+// fragments by ds_read_b64_tr_b16 (the reduction index is the LDS row); the 32-byte granules of a row are XOR-swizzled
+// by (row & 3) << 1 on the source side, which makes the transposing reads conflict-free without row padding.
+constexpr int WGG_MAX_LAYERS = 64;
+struct WgGangParams {
+    long long tbl[WGG_MAX_LAYERS][3];   // x, dy, dw addresses per layer: in the kernel arguments (1.5 KB), no table in memory
+    int L, M, ldx, ldy, Ci, Co;
+    int tiles_ci, tiles;    // tiles per layer
+    int KS;                 // K-steps (32 pixels) per layer
+    int R;                  // K-steps per gang
+    int gangs;              // ranges of the (layer, pixel) space
+    int gpx;                // > 0: gangs per XCD -- the T workgroups of a gang sit on ONE XCD (same blockIdx % 8), so the
+                            // rows the T tiles share come out of that XCD's L2 (each dy / x row is wanted by 3 of the 9
+                            // tiles of a 728 x 728 layer; spread over the XCDs every one of them went to the fabric and
+                            // the launch was bound by that traffic at 390 TFLOP/s)
+};
+
+constexpr int WGG_PIX = 32, WGG_ROWB = 512, WGG_OP = WGG_PIX * WGG_ROWB, WGG_STAGE = 2 * WGG_OP, WGG_NBUF = 4;
+
+__global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    constexpr int GROUP = 4, DIST = WGG_NBUF - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;      // 2 x 4 waves: 128 (co) x 64 (ci) each
+    int gang, member;
+    if (P.gpx > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int gi_ = slot / P.tiles;
+        member = slot - gi_ * P.tiles;
+        if (gi_ >= P.gpx) return;       // the XCD's left-over CUs
+        gang = xcd * P.gpx + gi_;
+    } else {
+        gang = blockIdx.x / P.tiles;
+        member = blockIdx.x - gang * P.tiles;
+    }
+    if (gang >= P.gangs) return;
+    const int tile_co = member / P.tiles_ci, tile_ci = member - tile_co * P.tiles_ci;
+    const int co_base = tile_co * 256, ci_base = tile_ci * 256;
+    const long long total = (long long)P.L * P.KS;
+    long long g = (long long)gang * P.R;
+    const long long gend = min(g + (long long)P.R, total);
+
+    // DMA geometry of this lane: piece k (0, 1) of an operand covers tile rows 2*wave + 16*k + (lane >> 5)
+    const int rsub = lane >> 5, slot = lane & 31;
+    const int sw = ((wave & 1) * 2 + rsub) & 3;             // (row & 3) of both pieces
+    const int chunk = slot ^ (sw << 2);                     // source 16-byte chunk that lands in LDS slot `slot`
+    const int row_a = 2 * wave + rsub;
+    const bool a_ok = co_base + chunk * 8 < P.Co, b_ok = ci_base + chunk * 8 < P.Ci;
+    // fragment read geometry (see wgrad_mma)
+    const int gi = lane >> 4, ii = lane & 15, qq = ii >> 2, pp = ii & 3;
+    const int cb = (gi & 1) * 16, hh = gi >> 1;
+    // per-lane LDS byte offsets of the fragments inside an operand tile, K sub-step 0, low half (the XOR moves bits 6-7
+    // only, where the fragment index i / j lives: one register per fragment, everything else is an immediate)
+    int off_a[4], off_b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) off_a[i] = (8 * hh + qq) * WGG_ROWB + (((wave_m * 128 + i * 32 + cb + 4 * pp) * 2) ^ (qq << 6));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) off_b[j] = WGG_OP + (8 * hh + qq) * WGG_ROWB + (((wave_n * 64 + j * 32 + cb + 4 * pp) * 2) ^ (qq << 6));
+
+    while (g < gend) {
+        const int l = (int)(g / P.KS);
+        const int ks0 = (int)(g - (long long)l * P.KS);
+        const int ks1 = (int)min((long long)P.KS, (long long)ks0 + (gend - g));
+        const bf16_t* xp = reinterpret_cast<const bf16_t*>(P.tbl[l][0]);
+        const bf16_t* dyp = reinterpret_cast<const bf16_t*>(P.tbl[l][1]);
+        float* dw = reinterpret_cast<float*>(P.tbl[l][2]);
+        // descriptors rebased to the segment's first pixel; rows beyond M are out of range = zeros
+        const long long p0 = (long long)ks0 * WGG_PIX;
+        const long long rem_a = (((long long)P.M - p0 - 1) * P.ldy + P.Co) * 2, rem_b = (((long long)P.M - p0 - 1) * P.ldx + P.Ci) * 2;
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(dyp + p0 * P.ldy), 0, (int)(rem_a < 0x7fffffffLL ? rem_a : 0x7fffffffLL), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(xp + p0 * P.ldx), 0, (int)(rem_b < 0x7fffffffLL ? rem_b : 0x7fffffffLL), 0x00020000);
+        int va[2], vb[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            va[k] = a_ok ? ((row_a + 16 * k) * P.ldy + co_base + chunk * 8) * 2 : OOB;
+            vb[k] = b_ok ? ((row_a + 16 * k) * P.ldx + ci_base + chunk * 8) * 2 : OOB;
+        }
+        const int step_a = WGG_PIX * P.ldy * 2, step_b = WGG_PIX * P.ldx * 2;
+        auto piece = [&](int buf, int pi) {   // pi compile-time: 0, 1 = dy pieces, 2, 3 = x pieces
+            char* st = smem + buf * WGG_STAGE + (pi >= 2 ? WGG_OP : 0) + (2 * wave + 16 * (pi & 1)) * WGG_ROWB;
+            if (pi < 2) { dma16(rs_a, st, va[pi]); va[pi] += step_a; }
+            else { dma16(rs_b, st, vb[pi - 2]); vb[pi - 2] += step_b; }
+        };
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int KT = ks1 - ks0;
+        __syncthreads();   // the previous segment's readers are done with the ring
+#pragma unroll
+        for (int s_ = 0; s_ < DIST; ++s_)
+            if (s_ < KT) {
+#pragma unroll
+                for (int pi = 0; pi < GROUP; ++pi) piece(s_, pi);
+            }
+        int buf = 0, nbuf = DIST % WGG_NBUF;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int ahead = KT - 1 - kt;
+            if (ahead >= 2) wait_vmcnt<2 * GROUP>();
+            else if (ahead >= 1) wait_vmcnt<GROUP>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const bool more = kt + DIST < KT;
+            const char* st = smem + buf * WGG_STAGE;
+            auto frag = [&](int off) -> bf16x8 {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off + 4 * WGG_ROWB));
+                const s16x8 tt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                return __builtin_bit_cast(bf16x8, tt);
+            };
+            // both 16-pixel halves' fragments: the first half is read behind the barrier, the second while the first
+            // half's MFMAs run (a read issued right in front of its MFMAs exposed the LDS latency eight times per step)
+            bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = frag(off_b[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = frag(off_a[i]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && (i & 1) == 0) piece(nbuf, ks * 2 + (i >> 1));   // 4 pieces over the 8 MFMA groups of a step
+                    if (ks == 0 && i == 0) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) fb[1][j] = frag(off_b[j] + 16 * WGG_ROWB);
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) fa[1][i2] = frag(off_a[i2] + 16 * WGG_ROWB);
+                    }
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            buf = (buf + 1 == WGG_NBUF) ? 0 : buf + 1;
+            nbuf = (nbuf + 1 == WGG_NBUF) ? 0 : nbuf + 1;
+        }
+        // flush: 32x32 accumulator layout: col = lane & 31 (ci), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (co).
+        // Buffer atomics over a descriptor of exactly this layer's dW: rows beyond Cout fall out of its range, lanes
+        // beyond Cin carry the out-of-range marker -- no exec-mask branches, one VALU add per atomic.
+        {
+            const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(dw, 0, P.Co * P.Ci * 4, 0x00020000);
+            const int c32 = lane & 31, h2 = lane >> 5;
+            const int rowb = P.Ci * 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci = ci_base + wave_n * 64 + j * 32 + c32;
+                int lane_off = ci < P.Ci ? ((co_base + wave_m * 128 + 4 * h2) * P.Ci + ci) * 4 : OOB;
+                asm volatile("" : "+v"(lane_off));   // keeps the 64 derived offsets out of the segment loop's invariants (they spilled)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][e], rs_w, lane_off + (i * 32 + (e & 3) + 8 * (e >> 2)) * rowb, 0, 0);
+            }
+        }
+        g += KT;
+    }
+}
+
 // ------------------------------------------------------- batched weight packing
 // Per dense-conv layer: src [K][RS][C] (the flat bf16/fp32 copy of the master weights)
 //   -> dst_k [K][RS][Cp]  forward operand, reduction dim zero-padded to the K-step granule
@@ -1847,6 +2029,51 @@ extern "C" int bg_conv_debug_stamps(void* buf) { g_dbg_stamps = (unsigned long l
 extern "C" int bg_conv_set_variant(int32_t variant) {
     BG_CHECK_ARG(variant == -1 || variant == 0 || variant == 2, "bg_conv_set_variant: %d is not one of -1, 0, 2", variant);
     g_conv_variant = variant;
+    return BG_OK;
+}
+
+extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, int32_t n_layers, int64_t M, int32_t Cin,
+                                           int32_t Cout, int32_t ldx, int32_t ldy, void* stream) {
+    BG_CHECK_ARG(dtype == BG_BF16, "bg_conv2d_bwd_weight_grouped: bf16 operands only (the transposing LDS reads)");
+    BG_CHECK_ARG(tbl && n_layers >= 1 && M >= 1 && M < (1LL << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 &&
+                 ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, "bg_conv2d_bwd_weight_grouped: bad arguments");
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  WGG_NBUF * WGG_STAGE);
+        once = true;
+    }
+    for (int l0 = 0; l0 < n_layers; l0 += WGG_MAX_LAYERS) {     // the addresses travel in the kernel arguments: 64 layers per launch
+        WgGangParams P{};
+        P.L = std::min(WGG_MAX_LAYERS, n_layers - l0);
+        for (int l = 0; l < P.L; ++l)
+            for (int k = 0; k < 3; ++k) {
+                P.tbl[l][k] = tbl[(long long)(l0 + l) * 4 + k];
+                BG_CHECK_ARG(P.tbl[l][k] != 0 && (P.tbl[l][k] & 15) == 0, "bg_conv2d_bwd_weight_grouped: null/unaligned pointer in row %d", l0 + l);
+            }
+        P.M = (int)M; P.ldx = ldx; P.ldy = ldy; P.Ci = Cin; P.Co = Cout;
+        P.tiles_ci = (Cin + 255) / 256;
+        P.tiles = P.tiles_ci * ((Cout + 255) / 256);
+        BG_CHECK_ARG(P.tiles <= 256, "bg_conv2d_bwd_weight_grouped: more than 256 output tiles per layer");
+        P.KS = (int)((M + WGG_PIX - 1) / WGG_PIX);
+        const long long total = (long long)P.L * P.KS;
+        // XCD-local gangs only on request: measured, the launch is bound by its K loop, not by the fabric -- the same time
+        // per workgroup either way, and the spread form uses 252 of the CUs where 3 gangs of 9 per XCD use 216 (695
+        // against 615 TFLOP/s)
+        static const bool xcd_local = getenv("BGAMD_WGG_XCD_LOCAL") != nullptr;
+        P.gpx = xcd_local && P.tiles <= 32 && P.tiles > 1 ? 32 / P.tiles : 0;
+        long long gangs = P.gpx ? 8 * P.gpx : 256 / P.tiles;            // one workgroup per CU
+        // A group of at least as many layers as gangs gives every gang a range of at least one layer: every dW tile then
+        // receives at most two adds (order-independent: bit-reproducible).  Smaller groups keep all the gangs -- several
+        // ranges per layer, their adds land in any order.  At least 8 K-steps per range.
+        if (total / gangs < 8) gangs = std::max<long long>(1, total / 8);
+        P.R = (int)((total + gangs - 1) / gangs);
+        gangs = (total + P.R - 1) / P.R;
+        P.gangs = (int)gangs;
+        const long long grid = P.gpx ? 256 : gangs * P.tiles;
+        hipLaunchKernelGGL(wgrad_gang_kernel, dim3((unsigned)grid), dim3(512), WGG_NBUF * WGG_STAGE, (hipStream_t)stream, P);
+        BG_CHECK_LAUNCH("wgrad_gang_kernel");
+    }
     return BG_OK;
 }
 

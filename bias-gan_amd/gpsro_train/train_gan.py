@@ -175,7 +175,114 @@ class GANTrainer:
 
         D's optimiser step is issued inside g_step after the generator forward has
         been enqueued: the generator forward does not read D, so under data
-        parallelism D's gradient all-reduce runs on the RCCL stream beneath it."""
+        parallelism D's gradient all-reduce runs on the RCCL stream beneath it.
+
+        Where the step qualifies (_graph_ok) it is captured into ONE hipGraph on its third call and replayed
+        afterwards: ~2 400 launches become one, the host's ~20 us per launch (Python, ctypes, autograd) disappears
+        from the step and the gaps between dependent kernels shrink to the hardware's."""
+        if self._graph_ok(inputs, outputs_real, masks):
+            return self._graph_step(inputs, outputs_real, masks, labels, eta)
+        return self._eager_step(inputs, outputs_real, masks, labels, eta)
+
+    # -- whole-step hipGraph ---------------------------------------------------------------------------
+    def _graph_ok(self, inputs, outputs_real, masks):
+        import os
+        from .. import _lib as L
+        mode = os.environ.get("BGAMD_STEP_GRAPH")
+        if mode == "0" or L.PROFILE is not None or not inputs.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        if isinstance(self.generator, DistributedModel) or isinstance(self.discriminator, DistributedModel):
+            return False        # the gradient all-reduces are not captured: data-parallel runs stay eager
+        g = _unwrap(self.generator)
+        if getattr(g, "noise_dimensions", 0) and not getattr(g, "noise_on_device", False):
+            return False        # host RNG draws inside forward()
+        if self.loss_type_gan not in ("ModifiedMinMax", "Wasserstein") or not (self._train_d and self._train_g):
+            return False
+        if type(self.g_opt).__name__ != "FusedAdam" or type(self.d_opt).__name__ != "FusedAdam":
+            return False
+        # unset: the host-bound regime (fields of at most 2^22 elements per batch); 1: every size
+        return mode == "1" or inputs.numel() <= (1 << 22)
+
+    def _graph_step(self, inputs, outputs_real, masks, labels, eta):
+        from ..runtime import StatsPool as _SP
+        s = self.step_count
+        train_g = (s < self.warmup) or (s % self.freq_g == 0)
+        train_d = (s >= self.warmup) and (s % self.freq_d == 0)
+        key = (tuple(inputs.shape), inputs.dtype, tuple(outputs_real.shape), masks is not None, train_g, train_d, s < self.warmup,
+               id(getattr(_unwrap(self.generator), "_bg_arena", None)), id(getattr(_unwrap(self.discriminator), "_bg_arena", None)))
+        if not hasattr(self, "_graphs"):
+            self._graphs, self._graph_seen = {}, {}
+        e = self._graphs.get(key)
+        if e is None and self._graph_seen.get(key, 0) < 2:       # two eager steps first: arenas, allocator, lazy state
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            return self._eager_step(inputs, outputs_real, masks, labels, eta)
+        # the host's random draws, in the eager order (GANLoss.d_loss draws fake, real, swap: utils/losses.py; the
+        # gradient penalty draws eta: deeplab_gan.py:99); the swap exchanges the two label tensors -- no branch in the graph
+        n = outputs_real.shape[0]
+        lab = None
+        if train_d and self.loss_type_gan == "ModifiedMinMax":
+            lf, lr_, swap = labels if labels is not None else self.criterion_gan.draw_labels()
+            lab = (lr_, lf) if swap else (lf, lr_)
+        if train_d and self.loss_type_gan == "Wasserstein" and eta is None:
+            eta = torch.distributions.uniform.Uniform(0., 1.).rsample((n, 1, 1, 1))
+        dev = inputs.device
+        if e is None:
+            e = {"x": inputs.clone(), "y": outputs_real.clone(), "m": None if masks is None else masks.clone(),
+                 "lab": None if lab is None else tuple(t.to(dev).clone() for t in lab),
+                 "eta": None if eta is None or self.loss_type_gan != "Wasserstein" else eta.to(dev).clone()}
+        else:
+            e["x"].copy_(inputs, non_blocking=True)
+            e["y"].copy_(outputs_real, non_blocking=True)
+            if masks is not None:
+                e["m"].copy_(masks, non_blocking=True)
+            if lab is not None:
+                for dst, src in zip(e["lab"], lab):
+                    dst.copy_(src.pin_memory() if not src.is_cuda else src, non_blocking=True)
+            if e["eta"] is not None:
+                e["eta"].copy_(eta.pin_memory() if not eta.is_cuda else eta, non_blocking=True)
+        opts = ([self.d_opt] if train_d else []) + ([self.g_opt] if train_g else [])
+        for o in opts:
+            o.prepare_replay()           # step count, lr and bias corrections of THIS step -> device
+        pool = _SP.get(dev)
+        if "graph" not in e:
+            self._capture(e, key, opts, pool)
+        else:
+            pool.used = e["pool_after"]
+            for m_, k in e["nbt"]:
+                m_.__dict__["_bg_nbt_pending"] = m_.__dict__.get("_bg_nbt_pending", 0) + k
+            e["graph"].replay()
+            if train_d and self.d_scheduler is not None:
+                self.d_scheduler.step()
+            if train_g and self.g_scheduler is not None:
+                self.g_scheduler.step()
+            self.step_count += 1
+        self.last_d_acc = e["acc"]
+        return e["d_loss"], e["g_loss"]
+
+    def _capture(self, e, key, opts, pool):
+        import torch.nn as nn
+        bns = [m for net in (self.generator, self.discriminator) for m in _unwrap(net).modules()
+               if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        before = [m.__dict__.get("_bg_nbt_pending", 0) for m in bns]
+        for net in (self.generator, self.discriminator):       # packed weight copies current before the graph starts
+            _unwrap(net).arena().sync()
+        labels = None if e["lab"] is None else (e["lab"][0], e["lab"][1], False)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        for o in opts:
+            o.capturing = True
+        try:
+            with torch.cuda.graph(g):
+                d_loss, g_loss = self._eager_step(e["x"], e["y"], e["m"], labels, e["eta"])
+        finally:
+            for o in opts:
+                o.capturing = False
+        e.update(graph=g, d_loss=d_loss, g_loss=g_loss, acc=self.last_d_acc, pool_after=pool.used,
+                 nbt=[(m, m.__dict__.get("_bg_nbt_pending", 0) - b) for m, b in zip(bns, before) if m.__dict__.get("_bg_nbt_pending", 0) != b])
+        self._graphs[key] = e
+        g.replay()                      # capture records, it does not execute
+
+    def _eager_step(self, inputs, outputs_real, masks=None, labels=None, eta=None):
         StatsPool.reset_all()   # one fill clears every statistic accumulator of the previous step
         s = self.step_count
         train_generator = (s < self.warmup) or (s % self.freq_g == 0)            # train_gan.py:247

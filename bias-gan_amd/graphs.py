@@ -39,6 +39,8 @@ class NoGradGraph:
     def enabled_for(self, args) -> bool:
         if _MODE == "0" or L.PROFILE is not None or not all(a.is_cuda for a in args):
             return False
+        if torch.cuda.is_current_stream_capturing():     # inside a captured training step: no nested graph
+            return False
         root = _unwrap(self.module)
         if getattr(root, "noise_dimensions", 0):       # host RNG draws inside forward(): not capturable
             return False

@@ -132,12 +132,81 @@ def wgrad_call(dev, tensors, name, *args):
 
 
 def wgrad_join(key=None):
-    """Make the current stream wait for the weight-gradient stream(s)."""
-    for k in ([key] if key is not None else list(_WG_STREAMS)):
+    """Make the current stream wait for the weight-gradient stream(s) (after issuing the grouped launches that were
+    collected during this backward pass)."""
+    for k in ([key] if key is not None else list(set(_WG_STREAMS) | set(_WG_GROUPS))):
+        wgrad_group_flush(k)
         ent = _WG_STREAMS.get(k)
         if ent is not None:
             torch.cuda.current_stream(ent[0].device).wait_stream(ent[0])
         _WG_PENDING.discard(k)
+
+
+# Pointwise (1x1) weight gradients are not launched layer by layer: a single 728 x 728 layer has 9 output tiles, so it can
+# only fill the chip by splitting its pixels over many workgroups that all add a copy of dW with float atomics.  They are
+# collected per shape during the backward pass and issued as ONE launch per shape when the pass ends
+# (bg_conv2d_bwd_weight_grouped: the 48 + 2 identical middle-flow layers are one launch whose workgroups each keep a
+# dW tile in registers over a whole layer).  BGAMD_WGRAD_GROUP=0 restores the per-layer launches.
+_WG_GROUPS = {}
+_WG_GROUP_ENABLED = _os.environ.get("BGAMD_WGRAD_GROUP", "1") != "0"
+
+
+def wgrad_group_ok(dtype, kh, kw, stride, pad, dil, has_bias) -> bool:
+    return (_WG_GROUP_ENABLED and dtype == torch.bfloat16 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and dil == 1
+            and not has_bias)
+
+
+def wgrad_group_add(dev, x, g, dw_ptr, rows, cin, cout, desc):
+    """Queue dW += g^T x of one pointwise layer for the end-of-backward grouped launch."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _WG_PENDING:
+        _WG_PENDING.add(key)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
+    sig = (rows, cin, cout, ld_of(x), ld_of(g))
+    _WG_GROUPS.setdefault(key, {}).setdefault(sig, []).append((x, g, dw_ptr, desc))
+
+
+def _gang_pays(n_layers, cin, cout) -> bool:
+    """Measured (scripts/bench_wgrad.py): the gang launch beats the per-layer kernel for groups of layers (1.6-2.0x on
+    the 48 middle-flow layers) and for single layers with many output tiles (1536 x 1536 and up: 1.1-1.3x); a single
+    layer of up to 12 tiles is 0.7-0.9x (one range per gang is too short against its flush)."""
+    tiles = (-(-cin // 256)) * (-(-cout // 256))
+    if cin * cout < 0.7 * tiles * 65536:       # 256 x 256 tiles mostly padding (128-channel layers): 0.3-0.5x
+        return False
+    return n_layers >= 2 or tiles >= 24
+
+
+def wgrad_group_flush(key):
+    groups = _WG_GROUPS.pop(key, None)
+    if not groups:
+        return
+    dev = torch.device("cuda", key)
+    use_side = _WG_ENABLED and L.PROFILE is None
+    if use_side:
+        ent = _WG_STREAMS.get(key)
+        if ent is None:
+            side = torch.cuda.Stream(device=dev)
+            ent = _WG_STREAMS[key] = (side, side.cuda_stream)
+        side, raw = ent
+        side.wait_stream(torch.cuda.current_stream(dev))
+    for (rows, cin, cout, ldx, ldy), jobs in groups.items():
+        if use_side:
+            for x, g, _, _ in jobs:
+                x.record_stream(side)
+                g.record_stream(side)
+        if not _gang_pays(len(jobs), cin, cout):
+            for x, g, dwp, desc in jobs:
+                if use_side:
+                    L.call_on(raw, "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dwp, None)
+                else:
+                    L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dwp, None)
+            continue
+        # the addresses are read on the host during the call and travel in the kernel arguments: no table in device memory
+        tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), dwp, 0] for x, g, dwp, _ in jobs], dtype=torch.int64)
+        if use_side:
+            L.call_on(raw, "bg_conv2d_bwd_weight_grouped", L.BF16, tbl.data_ptr(), len(jobs), rows, cin, cout, ldx, ldy)
+        else:
+            L.call("bg_conv2d_bwd_weight_grouped", L.BF16, tbl.data_ptr(), len(jobs), rows, cin, cout, ldx, ldy)
 
 
 # ------------------------------------------------------------------ layout boundary
@@ -277,7 +346,10 @@ class Conv2dFn(torch.autograd.Function):
             if bslot is not None and ctx.needs_input_grad[2]:
                 arena.ensure_grad(bslot)
                 dbias = arena.grad_ptr(bslot)
-            wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
+            if wgrad_group_ok(xdtype, kh, kw, stride, pad, dil, dbias is not None) and x.shape[3] == cin and g.shape[3] == kp:
+                wgrad_group_add(xdev, x, g, arena.grad_ptr(wslot), n * h * w, cin, kp, desc)
+            else:
+                wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
         return dx, None, None, None, None, None, None, None, None, None
 
 

@@ -21,6 +21,26 @@ class FusedAdam(optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled))
         self._mom = {}     # id(arena) -> (arena, exp_avg flat, exp_avg_sq flat): the arena reference keeps the key valid
         self._t = 0
+        self._hyper = {}   # id(arena) -> device [4] floats {lr, bias_corr1, bias_corr2, grad_scale} (captured steps)
+        self.capturing = False   # True while a training step is captured into a hipGraph (gpsro_train.train_gan)
+
+    # -- captured (hipGraph) steps -------------------------------------------------------------------
+    # A replayed step cannot take lr / bias corrections from launch arguments (they are baked in at capture), so the
+    # captured launch is bg_adam_step_dev, which reads them from four device floats; prepare_replay() advances the step
+    # count and rewrites those floats before the capture and before every replay.
+    def _hyper_of(self, a):
+        h = self._hyper.get(id(a))
+        if h is None or h.device != a.master.device:
+            h = self._hyper[id(a)] = torch.zeros(4, dtype=torch.float32, device=a.master.device)
+        return h
+
+    def prepare_replay(self):
+        self._t += 1
+        for a, g, _ in self._arenas():
+            b1, b2 = g["betas"]
+            ddp = getattr(a, "ddp", None)
+            L.call("bg_set_floats", self._hyper_of(a).data_ptr(), 4, float(g["lr"]), 1.0 - b1 ** self._t, 1.0 - b2 ** self._t,
+                   1.0 if ddp is None else 1.0 / ddp.world_size)
 
     def _moments(self, a):
         """Flat first/second moment buffers over arena `a`.  If the parameters moved to a new arena since the moments
@@ -65,6 +85,8 @@ class FusedAdam(optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self.capturing:
+            return self._step_captured()
         self._t += 1
         for a, g, slots in self._arenas():
             b1, b2 = g["betas"]
@@ -83,6 +105,21 @@ class FusedAdam(optim.Optimizer):
                        float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), int(bool(g["decoupled"])), bc1,
                        bc2, scale)
             a.refresh_copies(cast=False)   # CRSK copies for the data-gradient GEMMs
+            a._synced_version = a.master._version
+
+    def _step_captured(self):
+        for a, g, slots in self._arenas():
+            b1, b2 = g["betas"]
+            m, v = self._moments(a)
+            if getattr(a, "ddp", None) is not None:
+                raise RuntimeError("FusedAdam: captured steps are single-process (the gradient all-reduce is not captured)")
+            full = len(slots) == len(a.slots)
+            segs = [(0, a.numel)] if full else [(s.off, s.numel) for s in slots]
+            for off, n in segs:
+                L.call("bg_adam_step_dev", a.master.data_ptr() + 4 * off, a.grad.data_ptr() + 4 * off, m.data_ptr() + 4 * off,
+                       v.data_ptr() + 4 * off, None if a.lp is None else a.lp.data_ptr() + 2 * off, n, self._hyper_of(a).data_ptr(),
+                       float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), int(bool(g["decoupled"])))
+            a.refresh_copies(cast=False)
             a._synced_version = a.master._version
 
     # -- checkpoint interchange ----------------------------------------------------------------------

@@ -97,6 +97,13 @@ int bg_conv2d_fwd_splitk(const bg_conv_desc* d, const void* x, const void* w, fl
 int bg_conv2d_bwd_data_splitk(const bg_conv_desc* d, const void* dy, const void* wt, float* ws, int32_t splits, void* stream);
 int bg_splitk_reduce(int32_t dtype, const float* ws, int32_t splits, int64_t rows, int32_t C, void* y, int32_t ldy, void* stream);
 int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* stream);
+/* Weight gradients of n_layers POINTWISE (1x1, stride 1) convolutions of one shape in one launch (bf16 operands):
+ * dw_l[Cout][Cin] (fp32) += dy_l^T x_l over the M pixels, for l < n_layers.  tbl (HOST memory, read during the call):
+ * n_layers rows of 4 int64 {x_l, dy_l, dw_l, 0} device addresses -- they travel in the kernel arguments.  The (layer, pixel) space is cut into equal ranges walked by gangs of one
+ * workgroup per output tile; a dw tile receives at most two float-atomic adds when the group holds more layers
+ * than ranges' worth of work (then the result is bit-reproducible), operands are read from HBM once.  No bias. */
+int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, int32_t n_layers, int64_t M, int32_t Cin, int32_t Cout,
+                                 int32_t ldx, int32_t ldy, void* stream);
 
 /* Reduction-dimension padding granule of the packed weight copies (elements). */
 int bg_conv_weight_kpad(int32_t dtype);
@@ -355,6 +362,13 @@ int bg_gp_penalty(const float* g, int32_t N, int32_t C, int32_t HW, float inv_no
 int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf16 copy or NULL */, int64_t n, float lr,
                  double beta1, double beta2, float eps, float weight_decay, int32_t decoupled, float bias_corr1,
                  float bias_corr2, float grad_scale, void* stream);
+/* The same update with its step-dependent scalars in device memory: hyper = {lr, bias_corr1, bias_corr2, grad_scale}
+ * (4 floats).  For a training step captured into a hipGraph: the host rewrites hyper before each replay. */
+/* dst[0..n) = v0..v3 (n <= 4), values in the launch arguments: how the host hands bg_adam_step_dev its scalars without a
+ * pinned staging buffer. */
+int bg_set_floats(float* dst, int32_t n, float v0, float v1, float v2, float v3, void* stream);
+int bg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, const float* hyper, double beta1,
+                     double beta2, float eps, float weight_decay, int32_t decoupled, void* stream);
 int bg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -446,6 +446,30 @@ def test_adam_matches_torch():
         assert torch.equal(plp.cpu(), p.cpu().to(torch.bfloat16))
 
 
+def test_adam_with_device_scalars_matches_launch_arguments():
+    """bg_adam_step_dev (lr / bias corrections / gradient scale read from four device floats written by bg_set_floats: the
+    form a captured training step replays) == bg_adam_step with the same numbers as launch arguments, bit for bit."""
+    n = 4099
+    g_ = torch.Generator().manual_seed(1)
+    p0, gr = torch.randn(n, generator=g_), torch.randn(n, generator=g_) * 1e-2
+    for decoupled in (0, 1):
+        ref = [t.to(DEV).clone() for t in (p0, torch.zeros(n), torch.zeros(n))]
+        dev = [t.to(DEV).clone() for t in (p0, torch.zeros(n), torch.zeros(n))]
+        lpa, lpb = (torch.zeros(n, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        hyper = torch.zeros(4, device=DEV)
+        gdev = gr.to(DEV)
+        for t in (1, 2, 3):
+            lr, bc1, bc2, sc = 1e-3 / t, 1 - 0.9 ** t, 1 - 0.999 ** t, 0.5
+            L.call("bg_adam_step", ref[0].data_ptr(), gdev.data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), lpa.data_ptr(), n, lr, 0.9,
+                   0.999, 1e-8, 1e-2, decoupled, bc1, bc2, sc)
+            L.call("bg_set_floats", hyper.data_ptr(), 4, lr, bc1, bc2, sc)
+            L.call("bg_adam_step_dev", dev[0].data_ptr(), gdev.data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), lpb.data_ptr(), n,
+                   hyper.data_ptr(), 0.9, 0.999, 1e-8, 1e-2, decoupled)
+        for a, b in zip(ref, dev):
+            assert torch.equal(a, b)
+        assert torch.equal(lpa, lpb)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c,cp,ld", [(16, 16, 32), (5, 8, 8), (20, 24, 40)])
 def test_layout_four_pixel_form(dtype, c, cp, ld):
@@ -593,6 +617,42 @@ def test_conv_fat_tile_variant(case, dtype):
     # same products, same fp32 accumulation per output element up to the order of the K-steps: the two tile families
     # agree far inside the test tolerance
     assert_close(outs[2][0][..., :cout], outs[0][0][..., :cout], 2e-6 if dtype == torch.float32 else 8e-3, "fat vs classic fwd")
+
+
+@pytest.mark.parametrize("case", [(3, 1000, 72, 200, 0), (5, 2 * 24 * 20, 728, 728, 16), (1, 4099, 264, 520, 8), (2, 77, 8, 8, 0),
+                                  (50, 6 * 12 * 8, 728, 728, 0)])
+def test_conv_wgrad_grouped(case):
+    """bg_conv2d_bwd_weight_grouped: dW_l += dy_l^T x_l for a group of same-shape pointwise layers in one launch (gangs of
+    one workgroup per 256 x 256 output tile walking the (layer, pixel) space), against fp32 matmuls of the same
+    bf16-representable operands and against the per-layer kernel; accumulation semantics; bit-reproducibility when the
+    group spans more layers than ranges (every tile then receives at most two commutative adds)."""
+    nl, m, cin, cout, slack = case
+    dtype = torch.bfloat16
+    g_ = torch.Generator(device=DEV).manual_seed(7)
+    ldx, ldy = cin + slack, cout + slack
+    xs = [torch.randn((m, ldx), generator=g_, device=DEV).to(dtype) for _ in range(nl)]
+    gs = [(torch.randn((m, ldy), generator=g_, device=DEV) / math.sqrt(m)).to(dtype) for _ in range(nl)]
+    dws = [torch.full((cout, cin), 0.5, device=DEV) for _ in range(nl)]
+    tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), d.data_ptr(), 0] for x, g, d in zip(xs, gs, dws)], dtype=torch.int64)
+    L.call("bg_conv2d_bwd_weight_grouped", L.BF16, tbl.data_ptr(), nl, m, cin, cout, ldx, ldy)
+    for l in range(nl):
+        ref = gs[l][:, :cout].float().t() @ xs[l][:, :cin].float()
+        assert_close((dws[l] - 0.5).cpu(), ref.cpu(), 2e-3, f"layer {l}")
+    first = [d.clone() for d in dws]
+    # per-layer kernel on the same operands
+    desc = L.ConvDesc(L.BF16, 1, 1, m, cin, 1, m, cout, 1, 1, 1, 0, 1, ldx, ldy)
+    dw1 = torch.zeros(cout, cin, device=DEV)
+    L.call("bg_conv2d_bwd_weight", desc, xs[0].data_ptr(), gs[0].data_ptr(), dw1.data_ptr(), None)
+    assert_close((first[0] - 0.5).cpu(), dw1.cpu(), 1e-4, "grouped vs per-layer")
+    # a second call accumulates; a repeated run on fresh buffers is bit-identical when nl >= 2 (ranges >= one layer)
+    L.call("bg_conv2d_bwd_weight_grouped", L.BF16, tbl.data_ptr(), nl, m, cin, cout, ldx, ldy)
+    assert_close((dws[0] - 0.5).cpu(), 2 * (first[0] - 0.5).cpu(), 1e-5, "accumulate")
+    if nl >= 256 // ((-(-cin // 256)) * (-(-cout // 256))):     # at least as many layers as gangs
+        again = [torch.full((cout, cin), 0.5, device=DEV) for _ in range(nl)]
+        tbl2 = torch.tensor([[x.data_ptr(), g.data_ptr(), d.data_ptr(), 0] for x, g, d in zip(xs, gs, again)], dtype=torch.int64)
+        L.call("bg_conv2d_bwd_weight_grouped", L.BF16, tbl2.data_ptr(), nl, m, cin, cout, ldx, ldy)
+        for a, b in zip(again, first):
+            assert torch.equal(a, b), "grouped weight gradient is not bit-reproducible"
 
 
 def test_conv_operands_beyond_2gib():

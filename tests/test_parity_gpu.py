@@ -606,6 +606,126 @@ def test_data_parallel_two_ranks_share_one_gpu():
     assert alone["G"] != res[0]["G"] and alone["D"] != res[0]["D"]
 
 
+def _signed_projection(i, v):
+    """sum(v * r), r a fixed +-1 vector per parameter: unlike sum |v| it sees WHICH way the elements moved."""
+    r = torch.randint(0, 2, (v.numel(),), generator=torch.Generator().manual_seed(1000 + i)).double() * 2 - 1
+    return float((v.detach().double().cpu().reshape(-1) * r).sum())
+
+
+def _ddp_oracle_worker(rank, world, port, q):
+    """One of two data-parallel ranks running ONE loop iteration on rank-local data with rank-local, seeded labels;
+    returns per-parameter checksums of D and G."""
+    import torch.distributed as dist
+    from bias_gan_amd.comm.distributed import comm as distcomm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      BGAMD_DIST_BACKEND="gloo")
+    c, h, w, n = 4, 64, 64, 2
+    cm = distcomm(mode="torchrun")
+    G, _ = build_generator(c, 11, F32)
+    D, _ = build_discriminator(c, h, w, 21, F32)
+    G.train(), D.train()
+    crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+    tr = GANTrainer(cm.DistributedModel(G), cm.DistributedModel(D), ph.get_optimizer(G.parameters(), "Adam", 1e-3, 1e-8, 1e-5),
+                    ph.get_optimizer(D.parameters(), "Adam", 1e-3, 1e-8, 1e-5), crit, losses.L1Loss())
+    torch.manual_seed(100 + rank)
+    labels = crit.draw_labels()
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 3000 + rank))
+    tr.step(x, y, labels=labels)
+    torch.cuda.synchronize()
+    out = {"D": {k: (cs(v)[1], _signed_projection(i, v)) for i, (k, v) in enumerate(D.named_parameters())},
+           "G": {k: (cs(v)[1], _signed_projection(i, v)) for i, (k, v) in enumerate(G.named_parameters())}}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_update_is_the_oracle_average():
+    """Row a15 pinned to the oracle: two ranks, different data and labels.  Expected update = Adam on the MEAN over the
+    ranks of the per-rank gradients (apex DDP averages, comm/distributed.py:195-199), computed here by two oracle
+    replicas; the alternative a broken reduction would produce (rank 0's own gradient) is checked to be distinguishable
+    and further away."""
+    import socket
+    import torch.multiprocessing as mp
+    c, h, w, n, lr = 4, 64, 64, 2, 1e-3
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_oracle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    # ---- the oracle: two replicas of the D-step, then of the G-step, gradients averaged
+    gspec, dspec = orc.generator_spec(c, c, 0, "batch"), orc.discriminator_spec(c, h, w, "batch")
+    gk, dk = orc.trainable_keys(gspec), orc.trainable_keys(dspec)
+    data, labs = [], []
+    for r in range(2):
+        data.append(orc.synthetic_fields(n, c, h, w, 3000 + r))
+        torch.manual_seed(100 + r)
+        labs.append(orc.draw_d_labels(n))
+    ctx_n = orc.NormCtx("batch", True)
+
+    def leaves(P, keys):
+        Q = dict(P)
+        for k in keys:
+            Q[k] = P[k].detach().clone().requires_grad_(True)
+        return Q
+
+    def updates(avg):
+        PG, PD = orc.fill_state(gspec, 11), orc.fill_state(dspec, 21)
+        ranks = (0, 1) if avg else (0,)
+        dg = []
+        for r in ranks:
+            x, y = data[r]
+            with torch.no_grad():
+                fake = orc.generator({k: v.clone() for k, v in PG.items()}, x, ctx_n)
+            Q = leaves({k: v.clone() for k, v in PD.items()}, dk)
+            lr_, _ = orc.discriminator(Q, y, ctx_n)
+            lf_, _ = orc.discriminator(Q, fake, ctx_n)
+            loss = orc.gan_d_loss("ModifiedMinMax", lr_, lf_, *labs[r])
+            dg.append(torch.autograd.grad(loss, [Q[k] for k in dk], allow_unused=True))
+        grads = {k: sum(g[i] for g in dg) / len(ranks) for i, k in enumerate(dk) if dg[0][i] is not None}
+        orc.Adam(dk, lr, 1e-8, 1e-5).step(PD, grads)
+        gg = []
+        for r in ranks:
+            x, y = data[r]
+            Q = leaves({k: v.clone() for k, v in PG.items()}, gk)
+            fake = orc.generator(Q, x, ctx_n)
+            lf_, _ = orc.discriminator({k: v.clone() for k, v in PD.items()}, fake, ctx_n)
+            loss = orc.gan_g_loss("ModifiedMinMax", lf_) + (fake - y).abs().mean()
+            gg.append(torch.autograd.grad(loss, [Q[k] for k in gk], allow_unused=True))
+        grads = {k: sum(g[i] for g in gg) / len(ranks) for i, k in enumerate(gk) if gg[0][i] is not None}
+        orc.Adam(gk, lr, 1e-8, 1e-5).step(PG, grads)
+        return PD, PG
+
+    PD_avg, PG_avg = updates(True)
+    PD_solo, PG_solo = updates(False)
+    for name, keys, P_avg, P_solo in (("D", dk, PD_avg, PD_solo), ("G", gk, PG_avg, PG_solo)):
+        closer = told_apart = 0
+        for i, k in enumerate(keys):
+            got, want, other = res[0][name][k][0], cs(P_avg[k])[1], cs(P_solo[k])[1]
+            # Adam's first step moves every element by +-lr; elements whose (averaged) gradient is within rounding
+            # noise of 0 may take the other sign: a few of them (4 lr + a share growing like sqrt(numel): measured 8 of
+            # the 728 entries of one middle-flow BatchNorm bias) on top of the relative bound
+            tol = 2e-4 * want + lr * (4 + 0.5 * P_avg[k].numel() ** 0.5)
+            if name == "D":      # G's gradients come through the freshly updated D: percent-level (see the checkpoint test)
+                assert abs(got - want) <= tol, (name, k, got, want)
+            # which update was applied: Adam's first step is +-lr per element whatever the gradient's size, so sum |p| is
+            # the same for the averaged and for rank 0's own gradient -- the signed projection is not
+            gp, wp, op = res[0][name][k][1], _signed_projection(i, P_avg[k]), _signed_projection(i, P_solo[k])
+            if abs(wp - op) > 20 * lr:
+                told_apart += 1
+                closer += abs(gp - wp) < abs(gp - op)
+        print(f"{name}: {told_apart} of {len(keys)} parameters tell the averaged update from rank 0's own; HIP result closer to the average for {closer}")
+        assert told_apart >= len(keys) // 4 and closer >= (0.9 if name == "D" else 0.7) * told_apart
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_nograd_generator_graph_replay(dtype):
     """The D-step's generator forward as a hipGraph replay (graphs.NoGradGraph) against the eager launches on the same
@@ -684,3 +804,58 @@ def test_training_steps_with_graph_replay():
     (de, ge), (dg, gg) = eager[1], graph[1]          # the capturing step: already behind one chaotic Adam update
     assert abs(de - dg) <= 1e-1 * abs(de) and abs(ge - gg) <= 5e-1 * abs(ge), (eager, graph)
     assert all(np.isfinite(v) and 0.0 < v < 50.0 for pair in graph for v in pair)
+
+
+@pytest.mark.parametrize("lr", [0.0, 1e-3])
+@pytest.mark.parametrize("mode", ["ModifiedMinMax", "Wasserstein"])
+def test_whole_step_graph_matches_eager(monkeypatch, mode, lr):
+    """GANTrainer.step captured into one hipGraph (third call) and replayed, against the eager schedule on the same seeds:
+    six steps, fp32, a multistep LR schedule that decays inside the replayed range, host-drawn labels / eta.
+    Training trajectories of these nets are not comparable run to run (float atomics in the weight gradients + Adam's
+    sign-like first steps: two EAGER runs already differ by percents in the second step's losses), so the arithmetic of
+    the replay is pinned with the learning rate at 0 -- every step's losses then depend on that step's inputs, labels
+    and eta only and must agree to rounding -- and the run with a real learning rate checks the host-side state a
+    replay has to advance (Adam step counts, LR schedule, BatchNorm counters) and that the weights move alike."""
+    c, h, w, n = 4, 64, 64, 2
+
+    def run(flag):
+        monkeypatch.setenv("BGAMD_STEP_GRAPH", flag)
+        G, _ = build_generator(c, 41, F32)
+        D, _ = build_discriminator(c, h, w, 42, F32)
+        G.train(), D.train()
+        crit = losses.GANLoss(mode, n, torch.device(DEV))
+        g_opt = ph.get_optimizer(G.parameters(), "Adam", lr, 1e-8, 0.0 if lr == 0 else 1e-5)
+        d_opt = ph.get_optimizer(D.parameters(), "AdamW", lr, 1e-8, 0.0 if lr == 0 else 1e-4)
+        sched = {"type": "multistep", "milestones": "2 4", "decay_rate": "0.5"}
+        tr = GANTrainer(G, D, g_opt, d_opt, crit, losses.L1Loss(), loss_type_gan=mode, loss_weight_gp=10.0,
+                        g_scheduler=ph.get_lr_schedule(lr, sched, g_opt), d_scheduler=ph.get_lr_schedule(lr, sched, d_opt))
+        g0, d0 = G.arena().master.clone() if False else None, None
+        out = []
+        for s_ in range(6):
+            torch.manual_seed(300 + s_)          # the step draws its labels / eta from the host RNG stream itself
+            x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 700 + s_))
+            d_loss, g_loss = tr.step(x, y)
+            out.append((float(d_loss), float(g_loss), float(tr.last_d_acc)))
+        torch.cuda.synchronize()
+        sd = G.state_dict()
+        return dict(losses=out, graphs=len(getattr(tr, "_graphs", {})), t=(g_opt._t, d_opt._t), lr=(g_opt.param_groups[0]["lr"], d_opt.param_groups[0]["lr"]),
+                    step=tr.step_count, nbt=int(sd["model.xception_features.bn1.num_batches_tracked"]),
+                    gw=cs(G.arena().master), dw=cs(D.arena().master), rm=sd["model.xception_features.bn1.running_mean"].cpu())
+
+    e, g = run("0"), run("1")
+    assert e["graphs"] == 0 and g["graphs"] == 1
+    for k in ("t", "lr", "step", "nbt"):
+        assert e[k] == g[k], (k, e[k], g[k])
+    assert e["t"] == (6, 6) and e["step"] == 6 and e["nbt"] == 12 and abs(e["lr"][0] - 0.25 * lr) < 1e-12
+    for i, (a, b) in enumerate(zip(e["losses"], g["losses"])):
+        print(f"lr {lr} step {i}: eager d {a[0]:.6f} g {a[1]:.6f} | graph d {b[0]:.6f} g {b[1]:.6f}")
+        if lr == 0:
+            assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]), (i, a, b)
+            assert a[2] == b[2]
+        else:
+            assert np.isfinite(b[0]) and np.isfinite(b[1]) and 0.0 < b[1] < 100.0
+    if lr == 0:
+        assert e["gw"][1] == g["gw"][1] and e["dw"][1] == g["dw"][1]
+        assert rel_err(g["rm"], e["rm"]) <= 1e-5
+    else:       # six +-lr-like moves of every weight: the abs-sums of both schedules grow alike
+        assert abs(e["gw"][1] - g["gw"][1]) <= 2e-3 * e["gw"][1] and abs(e["dw"][1] - g["dw"][1]) <= 2e-3 * e["dw"][1]
