@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--loss", default="mmm", choices=["mmm", "wgan-gp"],
                     help="mmm: ModifiedMinMax + L1 (configs[2], the headline); wgan-gp: Wasserstein + gradient penalty "
                          "(configs[3]: one more D forward and a data-gradient-only D backward per step)")
+    ap.add_argument("--data", default="resident", choices=["resident", "ring"],
+                    help="resident: two synthetic batches in HBM (the headline: inputs resident when the timed region starts); "
+                         "ring: every step's batch comes from .npy files (HWC fp32, one sample per file, the CAM layout) "
+                         "through the pinned-host -> HBM staging ring while the previous step runs; prints the file -> HBM "
+                         "rate and is compared with the resident figure (never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-floor", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -109,6 +114,55 @@ def cpu_baseline(c, h, w):
     return {"value": n / dt * frac, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"one G+D iteration of oracle/gan_oracle.py (fp32, PyTorch CPU ops) at {hs}x{ws}x{c}, batch {n}: "
                       f"{dt:.1f} s"}
+
+
+class RingFeed:
+    """The measured loop fed from files: sample k of a batch is data_in_<k>.npy / data_out_<k>.npy ([H, W, C] fp32, the
+    layout of the CAM files, cam_numpy_singlefile_dataset.py:90-99), written once from the synthetic batches.  next()
+    collects the batch whose reads were submitted one step ago and submits the following one: file -> pinned slot by the
+    ring's reader threads, slot -> HBM on the ring's copy stream, all under the running step."""
+
+    def __init__(self, batches, device_index, rank):
+        import tempfile
+        import numpy as np
+        from bias_gan_amd.data import numpy_reader as nr
+        self.dir = tempfile.mkdtemp(prefix=f"bgamd_ring_{rank}_")
+        self.sets = []
+        for b, (x, y) in enumerate(batches):
+            names = []
+            for k in range(x.shape[0]):
+                fi, fo = (os.path.join(self.dir, f"data_{t}_{b}_{k}.npy") for t in ("in", "out"))
+                np.save(fi, x[k].permute(1, 2, 0).contiguous().cpu().numpy())
+                np.save(fo, y[k].permute(1, 2, 0).contiguous().cpu().numpy())
+                names += [fi, fo]
+            self.sets.append(names)
+        self.n = batches[0][0].shape[0]
+        self.slots = 4 * self.n + 2                       # two batches of (in, out) samples in flight
+        self.threads = int(os.environ.get("BG_RING_THREADS", "8"))
+        self.reader = nr.numpy_reader(False, device_index, ring_slots=self.slots)
+        self.reader.num_intra_threads = self.threads
+        self.reader.parse(self.sets[0][0])
+        self.sample_bytes = os.path.getsize(self.sets[0][0])
+        self.turn = 0
+        self.bytes = 0
+        self._submit()
+
+    def _submit(self):
+        for f in self.sets[self.turn % len(self.sets)]:
+            self.reader.prefetch(f)
+        self.turn += 1
+
+    def next(self):
+        shape = (self.n, *self.reader.shape)                  # [N, H, W, C]: samples land in the rows of a batch buffer
+        dev = torch.device("cuda", torch.cuda.current_device())
+        xb, yb = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
+        for k in range(self.n):                               # submit order: in_0, out_0, in_1, ...
+            self.reader.get_prefetched(out=xb[k])
+            self.reader.get_prefetched(out=yb[k])
+        self._submit()
+        self.bytes += 2 * self.n * self.sample_bytes
+        # NCHW views of channels-last memory: the module boundary converts without a transpose (ops.ToInternal)
+        return xb.permute(0, 3, 1, 2), yb.permute(0, 3, 1, 2)
 
 
 def host_floor(c, n, dtype, device, mode):
@@ -202,6 +256,10 @@ def main():
                   + "; ".join(devs), file=sys.stderr, flush=True)
 
     batches = [synthetic_batch(n, c, h, w, seed + 1000 * i, device) for i in range(2)]
+    feed = None
+    if args.data == "ring":
+        feed = RingFeed(batches, local_rank, rank)
+        batches = None
 
     def sync_all():
         if world > 1:
@@ -213,15 +271,18 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"models built, {args.warmup} warm-up steps")
+    nxt = (lambda i: feed.next()) if feed is not None else (lambda i: batches[i % 2])
     for i in range(args.warmup):
-        trainer.step(*batches[i % 2])
+        trainer.step(*nxt(i))
     sync_all()
+    if feed is not None:
+        feed.bytes = 0
     note(f"timing {args.steps} steps")
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step durations (no host sync)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        d_loss, g_loss = trainer.step(*batches[i % 2])
+        d_loss, g_loss = trainer.step(*nxt(i))
         marks[i + 1].record()
     host_enqueue = time.perf_counter() - t0      # host time to ENQUEUE the steps (no device sync in the loop)
     sync_all()
@@ -244,7 +305,7 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": median_ms,   # median of per-step device times (HIP events)
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic" if feed is None else "synthetic, staged from .npy files through the ring every step",
         "config": {"workload": f"{h}x{w}x{c} synthetic fields, batch {n}/GPU, DeepLabv3+/Xception-65 generator "
                                "(Interpolate upsampler, noise_dimensions 0) + Xception-65/Linear discriminator, "
                                "BatchNorm, " + ("Wasserstein + gradient penalty (weight 10) + L1" if args.loss == "wgan-gp" else "ModifiedMinMax + L1")
@@ -253,6 +314,12 @@ def main():
                    "collective_backend": (dist.get_backend() if world > 1 else None)},
     }
 
+    if feed is not None:
+        out["staging"] = {"file_to_hbm_GBps": feed.bytes / elapsed * 1e-9, "bytes_per_step": feed.bytes / args.steps,
+                          "files_per_step": 2 * n, "reader_threads": feed.threads, "ring_slots": feed.slots,
+                          "note": "files read from the page cache by the ring's threads into pinned slots, H2D on the ring's copy "
+                                  "stream under the previous step; the step's stream waits on the slot events only"}
+        batches = [feed.next(), feed.next()]
     # ---- roofline: one extra (un-timed) step with HIP events around every C-ABI launch
     # (every rank runs the step -- it contains the gradient all-reduces -- rank 0 records)
     if not args.no_kernel_profile:
@@ -275,7 +342,22 @@ def main():
             f[1] += e0.elapsed_time(e1) * 1e-3
             f[2] += flops
             f[3] += nbytes
-        mfma = {k: v for k, v in fam.items() if k.startswith("bg_conv2d")}
+        # A GEMM launch is MFMA-bound when its arithmetic intensity (algorithmic FLOP per algorithmic byte, every
+        # operand moved once) is above the machine's ridge, peak MFMA / peak HBM = 2.5e15 / 8e12 = 312 FLOP/B (bf16);
+        # below it the same kernel is an HBM-bound copy with some arithmetic attached (the 128-channel 1x1 layers of the
+        # entry flow: 64 FLOP/B) and belongs under the HBM roofline: those launches are listed as '<entry point>[hbm]'
+        # with their algorithmic GB/s and are not part of the MFMA figure.
+        ridge = (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12 / 8e12
+        fam = {}
+        for name, flops, e0, e1, nbytes in recs:
+            if name.startswith("bg_conv2d") and nbytes > 0 and flops / nbytes < ridge:
+                name += "[hbm]"
+            f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
+            f[0] += 1
+            f[1] += e0.elapsed_time(e1) * 1e-3
+            f[2] += flops
+            f[3] += nbytes
+        mfma = {k: v for k, v in fam.items() if k.startswith("bg_conv2d") and not k.endswith("[hbm]")}
         dom = max(mfma, key=lambda k: mfma[k][1])
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same
         # command (profiles/*_pmc_hbm_traffic.json, FETCH_SIZE corrected per MI355X_MICROARCH.md);
@@ -293,7 +375,7 @@ def main():
         achieved = flops / secs * 1e-12
         walg = w_alg_tflop(h, w, c, args.loss)
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+            "bound": "mfma", "kernel": dom, "ridge_flop_per_byte": ridge, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": traffic,
             "traffic_source": None if traffic is None else "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "command (profiles/*_pmc_hbm_traffic.json); not re-measured in this run",

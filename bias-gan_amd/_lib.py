@@ -207,6 +207,13 @@ def _alg_bytes(name, a) -> float:
     """Algorithmic HBM bytes of one launch of an HBM-bound entry point: every operand
     element read or written exactly once."""
     nn = lambda *idx: sum(1 for i in idx if a[i] is not None)  # noqa: E731
+    if name == "bg_conv2d_bwd_weight_grouped":
+        return float(a[2]) * (float(a[3]) * (a[4] + a[5]) * 2 + 4.0 * a[4] * a[5])
+    if name.startswith("bg_conv2d"):     # every operand once: activation in, activation out, weights
+        d = a[0]
+        es = _es(d.dtype)
+        wbytes = d.Cout * d.Cin * d.KH * d.KW * (4 if name == "bg_conv2d_bwd_weight" else es)
+        return float(d.N) * (d.H * d.W * d.Cin + d.Ho * d.Wo * d.Cout) * es + wbytes
     if name.startswith("bg_dwconv3x3"):
         d = a[0]
         return float(d.N) * (d.H * d.W + d.Ho * d.Wo) * d.C * _es(d.dtype)

@@ -195,10 +195,16 @@ class numpy_reader:
             raise RuntimeError("numpy_reader.prefetch: every ring slot is in flight; call get_prefetched() first")
         self._pending.append(self._submit(filename, element_id))
 
-    def get_prefetched(self) -> torch.Tensor:
-        """The oldest prefetched sample (the current stream waits for its H2D copy, the host does not)."""
+    def get_prefetched(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The oldest prefetched sample (the current stream waits for its H2D copy, the host does not).  `out`: a
+        contiguous tensor of the sample's shape and dtype to receive it (a row of a batch buffer: no stacking copy)."""
         if not self._pending:
             raise RuntimeError("numpy_reader.get_prefetched: nothing was prefetched")
+        if out is not None:
+            if tuple(out.shape) != tuple(self._shape) or out.dtype != _DTYPES[self._info.dtype_code] or not out.is_contiguous():
+                raise ValueError("numpy_reader.get_prefetched: `out` must be a contiguous tensor of the sample's shape and dtype")
+            self._collect(self._pending.pop(0), out)
+            return out
         out = self._empty()
         self._collect(self._pending.pop(0), out)
         return out

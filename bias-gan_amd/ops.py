@@ -215,12 +215,18 @@ class ToInternal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cp: int, dtype: torch.dtype):
-        x = x.contiguous()
         if x.dtype != torch.float32:
             x = x.float()
         n, c, h, w = x.shape
         ctx.c = c
         y = new_act(n, h, w, cp, dtype, x.device)
+        xl = x.permute(0, 2, 3, 1)
+        if c == cp and xl.is_contiguous() and x.data_ptr() % 16 == 0:
+            # the caller's tensor is channels-last in memory (HWC files read by the staging ring, stacked: the layout
+            # of cam_numpy_singlefile_dataset.py:96-99 before its permute): no transpose, one cast pass
+            L.call("bg_cast_rows", L.F32, L.dt(dtype), x.data_ptr(), c, y.data_ptr(), ld_of(y), n * h * w, c)
+            return y
+        x = x.contiguous()
         L.call("bg_nchw_to_nhwc", L.dt(dtype), x.data_ptr(), y.data_ptr(), n, c, h * w, cp, ld_of(y))
         return y
 
