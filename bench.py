@@ -178,6 +178,8 @@ def host_floor(c, n, dtype, device, mode):
     from bias_gan_amd.utils import parsing_helpers as ph
     from bias_gan_amd import graphs
     old, graphs._MODE = graphs._MODE, "0"
+    old_env = os.environ.get("BGAMD_STEP_GRAPH")
+    os.environ["BGAMD_STEP_GRAPH"] = "0"          # the eager launch path is what is being timed
     try:
         with contextlib.redirect_stdout(sys.stderr):
             G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, os=16, pretrained=False, normalizer=nn.BatchNorm2d,
@@ -200,6 +202,10 @@ def host_floor(c, n, dtype, device, mode):
         return 1e3 * dt
     finally:
         graphs._MODE = old
+        if old_env is None:
+            os.environ.pop("BGAMD_STEP_GRAPH", None)
+        else:
+            os.environ["BGAMD_STEP_GRAPH"] = old_env
 
 
 def main():
@@ -367,7 +373,7 @@ def main():
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]
             for fam_name, rec in json.load(open(pj))["kernels"].items():
-                if dom.replace("_stats", "") in fam_name.split("+"):
+                if "fat tiles" in fam_name and dom.replace("_stats", "") in fam_name.split(" ")[0].split("+"):
                     traffic = rec["hbm_bytes_per_launch"]
         except Exception:
             traffic = None

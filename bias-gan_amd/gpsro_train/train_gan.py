@@ -200,8 +200,8 @@ class GANTrainer:
             return False
         if type(self.g_opt).__name__ != "FusedAdam" or type(self.d_opt).__name__ != "FusedAdam":
             return False
-        # unset: the host-bound regime (fields of at most 2^22 elements per batch); 1: every size
-        return mode == "1" or inputs.numel() <= (1 << 22)
+        # unset: the host-bound regime (batches of at most 2^24 field elements: 256x256x16 x 8 is 2^23); 1: every size
+        return mode == "1" or inputs.numel() <= (1 << 24)
 
     def _graph_step(self, inputs, outputs_real, masks, labels, eta):
         from ..runtime import StatsPool as _SP

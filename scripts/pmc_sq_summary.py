@@ -9,10 +9,16 @@ calls = collections.Counter()
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
         name = row["Kernel_Name"]
-        key = next((k for k in ("gemm_conv_dma_kernel", "wgrad_kernel", "dw_s1_kernel", "dw_bwd_weight", "norm_act_fwd",
+        key = next((k for k in ("gemm_conv_fat_kernel", "wgrad_gang_kernel", "gemm_conv_dma_kernel", "wgrad_kernel", "dw_s1_kernel", "dw_bwd_weight", "norm_act_fwd",
                                 "norm_act_bwd_apply", "colreduce") if k in name), None)
         if key is None:
             continue
+        if key == "gemm_conv_fat_kernel":     # split by tile variant: <T, BKB, MI, NJ, WM, WN, NBUF, PW1>
+            for tag, label in (("Li6ELi7ELi4ELi2E", "<384x224>"), ("Li4ELi7ELi4ELi2E", "<256x224>"), ("Li2ELi7ELi8ELi1E", "<256x112>"),
+                               ("Li2ELi7ELi4ELi2E", "<128x224>")):
+                if tag in name:
+                    key += label
+                    break
         if key == "gemm_conv_dma_kernel":     # split by tile variant
             for tag in ("Li256ELi128ELb0", "Li256ELi256ELb0", "Li128ELi256ELb0", "Li128ELi128ELb0", "Lb1"):
                 if tag in name:

@@ -5,8 +5,10 @@ bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact.
 import collections, csv, json, sys
 
 FAMILY = {  # kernel symbol fragment -> C-ABI entry points it implements
+    "gemm_conv_fat_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data (fat tiles: one 384/256-row tile per CU)",
+    "wgrad_gang_kernel": "bg_conv2d_bwd_weight_grouped",
     "gemm_conv_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data",
-    "gemm_conv_dma_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data",
+    "gemm_conv_dma_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data (64x64-per-wave tiles)",
     "wgrad_kernel": "bg_conv2d_bwd_weight",
     "dgrad_s2_smallc_kernel": "bg_conv2d_bwd_data(first layer: 3x3 stride 2, <= 16 channels)",
     "dw_s1_kernel": "bg_dwconv3x3_fwd+bg_dwconv3x3_bwd_data(stride 1, dilation 1)",
