@@ -382,6 +382,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(GemmConvParams P) {
     conv_epilogue<T>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
 }
 
+template <typename T, int MI, int NJ, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4 (&acc)[MI][NJ], int p_base, int rows_valid,
+                                                  int grp, int c_base, int wave_c, int wave_p, int lane, char* smem);
+
 // ------------------------------------------------------- LDS-DMA variant ----
 // Same tiling, swizzle, MFMA schedule and epilogue, but the operands travel
 // global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction,
@@ -621,7 +625,11 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
             }
         }
     } else {
-        conv_epilogue<T, TCH, TP>(P, acc, p_base, c_base, wave_c, wave_p, lane, smem);
+        // the fat tile's epilogue (LDS-transposed full-run stores through a rebased descriptor, branch-free): the pointer
+        // form above wrote every 128-byte line of the output in four 32-byte pieces from ~40 VALU instructions each
+        const int rows_valid = (int)min((long long)TP, P.M - p_base);
+        const int grp = P.stat_group_pix ? (int)(p_base / P.stat_group_pix) : 0;
+        conv_epilogue_fat<T, 4, 4, TCH / 64, PW>(P, acc, (int)p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
     }
 #endif
 }
@@ -699,8 +707,8 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
         __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
     const bool stats = P.stat_sum != nullptr;
     char* region = smem + wave * REGION;                               // this wave's transposition buffer
-    float* red = reinterpret_cast<float*>(smem + 8 * REGION);         // [wave_p][TM channels][2]
-    static_assert(8 * REGION + WN * TM * 8 <= 64 * 1024, "epilogue scratch");
+    float* red = reinterpret_cast<float*>(smem + WM * WN * REGION);   // [wave_p][TM channels][2]
+    static_assert(WM * WN * REGION + WN * TM * 8 <= 96 * 1024, "epilogue scratch must fit the smallest staging ring that uses it");
     __syncthreads();   // every wave is done reading the staging ring: reuse it
 
     // read-back geometry: chunk ci of the block's 16 * CPP is (pixel ci / CPP, 16-byte chunk ci % CPP)
@@ -1422,8 +1430,9 @@ struct WgGangParams {
                             // the launch was bound by that traffic at 390 TFLOP/s)
 };
 
-constexpr int WGG_PIX = 32, WGG_ROWB = 512, WGG_OP = WGG_PIX * WGG_ROWB, WGG_STAGE = 2 * WGG_OP, WGG_NBUF = 4;
+constexpr int WGG_PIX = 32, WGG_ROWB = 512, WGG_OP = WGG_PIX * WGG_ROWB, WGG_STAGE = 2 * WGG_OP;
 
+template <int WGG_NBUF>
 __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -1511,7 +1520,8 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
         int buf = 0, nbuf = DIST % WGG_NBUF;
         for (int kt = 0; kt < KT; ++kt) {
             const int ahead = KT - 1 - kt;
-            if (ahead >= 2) wait_vmcnt<2 * GROUP>();
+            if (DIST >= 4 && ahead >= 3) wait_vmcnt<3 * GROUP>();
+            else if (ahead >= 2) wait_vmcnt<2 * GROUP>();
             else if (ahead >= 1) wait_vmcnt<GROUP>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -1666,9 +1676,10 @@ int plan_fat(GemmConvParams& P, bool big) {   // big: an operand beyond the clas
     const int bk = 64 / (int)sizeof(T);
     const long long kt = (long long)P.KH * P.KW * ((P.CK + bk - 1) / bk);
     if (mode != 2 && !big && ((P.NO <= 128 && !fat128) || kt < 8 || P.M < 16384)) return 0;
-    // measured (scripts/bench_fat.py): the tap-walking variant on the decoder's 3x3 layers (hundreds of thousands of
-    // pixels, Cout 256) is 3-17 % behind the 256 x 256 classic tile; on the ASPP's few-pixel layers 13-15 % ahead
-    if (mode != 2 && !big && P.KH * P.KW > 1 && P.M >= 131072) return 0;
+    // measured (scripts/bench_fat.py): on hundreds of thousands of pixels with Cout <= 256 (the decoder's 3x3 layers, the
+    // 256 -> 256 pointwise layers at 288x192) the classic tiles are level or up to 17 % ahead; on the ASPP's few-pixel
+    // layers the fat tile is 13-15 % ahead
+    if (mode != 2 && !big && P.M >= 131072 && (P.KH * P.KW > 1 || P.NO <= 256)) return 0;
     const int groups = P.stat_group_pix ? (int)(P.M / P.stat_group_pix) : 1;
     const long long gp = P.M / groups;
     if (gp * groups != P.M || gp >= (1LL << 31)) return 0;
@@ -2037,10 +2048,11 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
     BG_CHECK_ARG(dtype == BG_BF16, "bg_conv2d_bwd_weight_grouped: bf16 operands only (the transposing LDS reads)");
     BG_CHECK_ARG(tbl && n_layers >= 1 && M >= 1 && M < (1LL << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 &&
                  ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, "bg_conv2d_bwd_weight_grouped: bad arguments");
+    static const int nbuf = getenv("BGAMD_WGG_NBUF") ? atoi(getenv("BGAMD_WGG_NBUF")) : 4;   // 4 or 5 stages of 32 KiB (measured: 5 is +2 % on the 48-layer group, -4 % on single layers)
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  WGG_NBUF * WGG_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WGG_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * WGG_STAGE);
         once = true;
     }
     for (int l0 = 0; l0 < n_layers; l0 += WGG_MAX_LAYERS) {     // the addresses travel in the kernel arguments: 64 layers per launch
@@ -2071,7 +2083,8 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
         gangs = (total + P.R - 1) / P.R;
         P.gangs = (int)gangs;
         const long long grid = P.gpx ? 256 : gangs * P.tiles;
-        hipLaunchKernelGGL(wgrad_gang_kernel, dim3((unsigned)grid), dim3(512), WGG_NBUF * WGG_STAGE, (hipStream_t)stream, P);
+        if (nbuf == 4) hipLaunchKernelGGL(wgrad_gang_kernel<4>, dim3((unsigned)grid), dim3(512), 4 * WGG_STAGE, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL(wgrad_gang_kernel<5>, dim3((unsigned)grid), dim3(512), 5 * WGG_STAGE, (hipStream_t)stream, P);
         BG_CHECK_LAUNCH("wgrad_gang_kernel");
     }
     return BG_OK;

@@ -5,5 +5,5 @@ timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "wgrad_gro
 rc=$?
 tail -n 3 gpurun_out/wg_tests.log
 [ $rc -ne 0 ] && exit $rc
-echo "== XCD-local gangs"; timeout -k 10 300 python scripts/bench_wgrad.py 2>&1 | grep -v amdgpu | tee gpurun_out/wg_bench.log
-echo "== spread"; BGAMD_WGG_SPREAD=1 timeout -k 10 300 python scripts/bench_wgrad.py 2>&1 | grep -v amdgpu | tee -a gpurun_out/wg_bench.log
+echo "== 5 stages"; timeout -k 10 300 python scripts/bench_wgrad.py 2>&1 | grep -v amdgpu | head -4 | tee gpurun_out/wg_bench.log
+echo "== 4 stages"; BGAMD_WGG_NBUF=4 timeout -k 10 300 python scripts/bench_wgrad.py 2>&1 | grep -v amdgpu | head -4 | tee -a gpurun_out/wg_bench.log
