@@ -70,16 +70,16 @@ class DistributedModel(nn.Module):
         super().__init__()
         self.module = module
         self.group = group
-        self._ready = False
+        self._ready = None      # the arena the broadcast / reducer were set up for
 
     def _prepare(self):
         arena = self.module.arena()
-        if not self._ready:
+        if self._ready is not arena:      # first call, or the arena was rebuilt (module.to(), set_compute_dtype())
             dist.broadcast(arena.master, src=0, group=self.group)
             arena.weights_changed()
             arena.sync()
             arena.ddp = FlatAllReduce(arena.grad, self.group)
-            self._ready = True
+            self._ready = arena
         return arena
 
     def forward(self, *a, **kw):

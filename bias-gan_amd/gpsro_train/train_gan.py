@@ -160,6 +160,10 @@ class GANTrainer:
                 g_loss = self.w_gan * gan_loss + self.w_reg * regression_loss
             self.g_opt.zero_grad()
             g_loss.backward()
+            if ahead is not None and ahead[0] is inputs:
+                # the early generator forward ran on the side stream, so autograd runs its backward nodes there too;
+                # with the weight-gradient stream switched off nothing else joins that stream before Adam reads the gradients
+                torch.cuda.current_stream(inputs.device).wait_stream(self._side)
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)

@@ -516,6 +516,22 @@ def test_validation_and_checkpoint_roundtrip(tmp_path, golden_dir):
     torch.manual_seed(5)
     vd, vg = tr.validate([(x0, y0), (x1, y1)], distcomm(mode="dummy"))
     assert np.isfinite(vd) and np.isfinite(vg) and tr.generator.training and tr.discriminator.training
+    # the same pass by the oracle in eval mode (running statistics) on the state the HIP path holds after its step:
+    # train_gan.py:330-398 averages the per-batch losses over the samples
+    PG = {k: v.detach().cpu().clone() for k, v in tr.generator.state_dict().items()}
+    PD = {k: v.detach().cpu().clone() for k, v in tr.discriminator.state_dict().items()}
+    ev = orc.NormCtx("batch", training=False)
+    torch.manual_seed(5)
+    od = og = 0.0
+    for xb, yb in ((x0, y0), (x1, y1)):
+        with torch.no_grad():
+            fake = orc.generator(PG, xb.cpu(), ev)
+            lr_, _ = orc.discriminator(PD, yb.cpu(), ev)
+            lf_, _ = orc.discriminator(PD, fake, ev)
+            od += float(orc.gan_d_loss("ModifiedMinMax", lr_, lf_, *orc.draw_d_labels(n))) / 2
+            og += float(orc.gan_g_loss("ModifiedMinMax", lf_) + (fake - yb.cpu()).abs().mean()) / 2
+    print(f"validation: HIP d {vd:.6f} g {vg:.6f} | oracle (eval mode) d {od:.6f} g {og:.6f}")
+    assert abs(vd - od) <= 1e-3 * abs(od) and abs(vg - og) <= 1e-3 * abs(og)
     after = tr.generator.state_dict()
     assert all(torch.equal(before[k], after[k]) for k in before)   # eval mode: no running-stat updates
     ck = str(tmp_path / "ck_step_1.cpt")
