@@ -80,6 +80,8 @@ struct Chunk {
 __device__ inline float lrelu_f(float z) { return z >= 0.f ? z : LRELU_SLOPE * z; }
 // activation codes of the norm_act entry points: 0 none, 1 LeakyReLU(0.2), 2 ReLU (PCBActiv3d, infill3d.py:103-106)
 __device__ inline float act_slope(int act) { return act == 2 ? 0.f : LRELU_SLOPE; }
+// slope s such that act(z) == max(z, s*z): identity 1, LeakyReLU 0.2, ReLU 0
+__device__ inline float act_max_slope(int act) { return act == 0 ? 1.f : act_slope(act); }
 __device__ inline float lrelu_grad_from_out(float y) { return y >= 0.f ? 1.f : LRELU_SLOPE; }
 
 __device__ inline float wave_sum(float v) {

@@ -6,6 +6,7 @@
 // wave with shuffles and finish with fp64 atomics (so var = E[x^2]-E[x]^2 is
 // evaluated in double and the result does not depend on how rows were split).
 #include "common.h"
+#include <initializer_list>
 
 namespace {
 
@@ -15,7 +16,7 @@ namespace {
 // grid: x = channel-vector blocks, y = row chunks inside a group, z = group.
 // No integer division anywhere on the per-element path.
 struct Tiling {
-    int tx, log_tx;      // channel vectors per block (power of two: 16, 32 or 64)
+    int tx, ty;          // channel vectors per block row, block rows (threads per block = tx * ty <= 256)
     int gx;              // blocks along channels
     int rows_per_block;  // rows walked by one block
     int gy;
@@ -26,19 +27,44 @@ inline int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-inline Tiling make_tiling(int dtype, int C, long long rows_per_group, int groups, int min_rows_per_thread,
-                          int target_blocks) {
-    const int cv = C / dtype_vec(dtype);
-    int best = 16, best_pad = 1 << 30;
-    for (int tx = 16; tx <= 64; tx *= 2) {
-        const int pad = (cv + tx - 1) / tx * tx;
-        if (pad <= best_pad) { best_pad = pad; best = tx; }
+// The pixel stride all operands of a launch share (0 if they differ or one is absent with another stride).
+inline int common_ld(std::initializer_list<int> lds) {
+    int ld = 0;
+    for (int v : lds) {
+        if (v <= 0) continue;
+        if (ld && v != ld) return 0;
+        ld = v;
     }
+    return ld;
+}
+
+// ld_common > 0: every operand is a whole-row tensor of that pixel stride (no channel slices of wider buffers), so
+// consecutive rows are consecutive in memory.  Then a block row is the WHOLE pixel row (tx = ld / VEC chunks, the pad
+// chunk's lanes idle) and the block's ty rows are one contiguous span: every wave load / store is 1 KiB of consecutive
+// bytes, like a plain copy.  With the power-of-two tiling below a wave touched four 256-byte pieces 1 472 bytes apart;
+// measured on the middle flow's 40 MB tensors a copy ran 1.5x faster than these kernels (scripts/bench_ew.py).
+inline Tiling make_tiling(int dtype, int C, long long rows_per_group, int groups, int min_rows_per_thread,
+                          int target_blocks, int ld_common = 0) {
+    const int vec = dtype_vec(dtype);
+    const int cv = C / vec;
+    static const int row_mode = env_int("BGAMD_EW_ROWMODE", 1);
     Tiling t;
-    t.tx = best;
-    t.log_tx = best == 16 ? 4 : (best == 32 ? 5 : 6);
-    t.gx = (cv + best - 1) / best;
-    const int ty = 256 / best;
+    const int cvl = ld_common / vec;
+    if (row_mode && ld_common > 0 && ld_common % vec == 0 && cvl > 16 && cvl <= 256 && ld_common - C < 64) {
+        t.tx = cvl;
+        t.ty = 256 / cvl;
+        t.gx = 1;
+    } else {
+        int best = 16, best_pad = 1 << 30;
+        for (int tx = 16; tx <= 64; tx *= 2) {
+            const int pad = (cv + tx - 1) / tx * tx;
+            if (pad <= best_pad) { best_pad = pad; best = tx; }
+        }
+        t.tx = best;
+        t.ty = 256 / best;
+        t.gx = (cv + best - 1) / best;
+    }
+    const int ty = t.ty;
     long long want = target_blocks / ((long long)t.gx * groups);
     if (want >= 8) want = want / 8 * 8;  // the grid is gx * roundup8(gy) blocks (BG_BLOCK_COORDS): stay within the target
     if (want < 1) want = 1;
@@ -81,6 +107,7 @@ __device__ __forceinline__ void norm_affine(float gamma, float beta, float mean,
 
 // ------------------------------------------------------------ column reduce --
 enum { RED_STATS = 0, RED_BWD = 1, RED_COLSUM = 2 };
+constexpr int RED_U = 4;  // rows in flight per thread and operand
 
 struct RedParams {
     const void* a;  // x (stats, colsum) | dy (bwd)
@@ -95,7 +122,7 @@ struct RedParams {
     long long rows_per_group;
     int rows_per_block;
     int C;
-    int tx, log_tx;
+    int tx, ty;
     double* o1;
     double* o2;
     float* of;  // colsum output
@@ -103,14 +130,16 @@ struct RedParams {
     int gx, gy;
 };
 
-template <typename T, int MODE>
+// SIGN (RED_BWD only): 0 no activation, 1 branch from the stored output b, 2 recomputed from c*scale+shift;
+// HASX (RED_BWD only): the g*xhat statistic is wanted (c given).  Compile-time: see norm_act_fwd_kernel.
+template <typename T, int MODE, int SIGN, bool HASX>
 __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int NS = (MODE == RED_COLSUM) ? 1 : 2;
     __shared__ float red[256 * VEC * NS];
-    const int lx = threadIdx.x & (P.tx - 1);
-    const int ly = threadIdx.x >> P.log_tx;
-    const int ty = 256 >> P.log_tx;
+    const int ly = (int)threadIdx.x / P.tx;
+    const int lx = (int)threadIdx.x - ly * P.tx;
+    const int ty = P.ty;
     BG_BLOCK_COORDS(P, bx, by);
     const int c = (bx * P.tx + lx) * VEC;
     const bool c_ok = c < P.C;
@@ -124,24 +153,41 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
     float mu[VEC], rs[VEC], sc[VEC], sh[VEC];
-    if (MODE == RED_BWD && c_ok) {
+    if (MODE == RED_BWD) {
+        // per-channel statistics once per block, lanes along channels, through LDS (see norm_act_fwd_kernel); the
+        // buffer is the reduction scratch, free until the row loop is over
+        const int row_w = P.tx * VEC;
+        for (int ch = threadIdx.x; ch < row_w; ch += (int)blockDim.x) {
+            const int cg = bx * row_w + ch;
+            float m = 0.f, r = 1.f, a = 1.f, b = 0.f;
+            if (cg < P.C) {
+                m = P.mean ? P.mean[(long long)g * P.C + cg] : 0.f;
+                r = P.rstd ? P.rstd[(long long)g * P.C + cg] : 1.f;
+                norm_affine(P.gamma ? P.gamma[cg] : 1.f, P.beta ? P.beta[cg] : 0.f, m, r, a, b);
+            }
+            red[ch] = m;
+            red[row_w + ch] = r;
+            red[2 * row_w + ch] = a;
+            red[3 * row_w + ch] = b;
+        }
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            mu[e] = P.mean ? P.mean[(long long)g * P.C + c + e] : 0.f;
-            rs[e] = P.rstd ? P.rstd[(long long)g * P.C + c + e] : 1.f;
-            norm_affine(P.gamma ? P.gamma[c + e] : 1.f, P.beta ? P.beta[c + e] : 0.f, mu[e], rs[e], sc[e], sh[e]);
+            mu[e] = red[lx * VEC + e];
+            rs[e] = red[row_w + lx * VEC + e];
+            sc[e] = red[2 * row_w + lx * VEC + e];
+            sh[e] = red[3 * row_w + lx * VEC + e];
         }
+        __syncthreads();
     }
     if (c_ok) {
         const T* a = reinterpret_cast<const T*>(P.a) + (gbase + r0 + ly) * P.lda + c;
         const T* b = P.b ? reinterpret_cast<const T*>(P.b) + (gbase + r0 + ly) * P.ldb + c : nullptr;
         const T* cc = P.c ? reinterpret_cast<const T*>(P.c) + (gbase + r0 + ly) * P.ldc + c : nullptr;
         const long long sa = (long long)ty * P.lda, sb = (long long)ty * P.ldb, s_c = (long long)ty * P.ldc;
-#pragma unroll 4
-        for (long long r = r0 + ly; r < r1; r += ty) {
-            Chunk<T> va;
-            va.load(a);
-            a += sa;
+        constexpr bool ld_b = MODE == RED_BWD && SIGN == 1, ld_c = MODE == RED_BWD && (HASX || SIGN == 2);
+        const float slope = act_slope(P.act);
+        auto row = [&](const Chunk<T>& va, const Chunk<T>& vy, const Chunk<T>& vx) {
             if (MODE == RED_STATS) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
@@ -153,17 +199,55 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) s1[e] += va.get(e);
             } else {
-                Chunk<T> vy, vx;
-                if (P.act && b) { vy.load(b); b += sb; }
-                if (cc) { vx.load(cc); cc += s_c; }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float gg = va.get(e);
-                    if (P.act) gg *= ((b ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : act_slope(P.act));
+                    if (SIGN == 1) gg *= vy.get(e) > 0.f ? 1.f : slope;
+                    if (SIGN == 2) gg *= fmaf(vx.get(e), sc[e], sh[e]) > 0.f ? 1.f : slope;
                     s1[e] += gg;
-                    if (cc) s2[e] = fmaf(gg, (vx.get(e) - mu[e]) * rs[e], s2[e]);
+                    if (HASX) s2[e] = fmaf(gg, (vx.get(e) - mu[e]) * rs[e], s2[e]);
                 }
             }
+        };
+        auto load = [&](Chunk<T>* va, Chunk<T>* vy, Chunk<T>* vx) {
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                va[u].load(a + u * sa);
+                if (ld_b) vy[u].load(b + u * sb);
+                if (ld_c) vx[u].load(cc + u * s_c);
+            }
+        };
+        // software-pipelined batches of RED_U rows per operand (the compiler's own unrolling of the one-row loop waited
+        // for each row's loads before issuing the next row's)
+        long long r = r0 + ly;
+        const long long step = RED_U * (long long)ty;
+        Chunk<T> va[RED_U], vy[RED_U], vx[RED_U];
+        bool have = r + step - ty < r1;
+        if (have) load(va, vy, vx);
+        while (have) {
+            Chunk<T> ca[RED_U], cy[RED_U], cx[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                ca[u] = va[u];
+                if (ld_b) cy[u] = vy[u];
+                if (ld_c) cx[u] = vx[u];
+            }
+            r += step;
+            a += RED_U * sa;
+            if (ld_b) b += RED_U * sb;
+            if (ld_c) cc += RED_U * s_c;
+            have = r + step - ty < r1;
+            if (have) load(va, vy, vx);
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) row(ca[u], cy[u], cx[u]);
+        }
+        for (; r < r1; r += ty) {
+            Chunk<T> v1, v2, v3;
+            v1.load(a);
+            a += sa;
+            if (ld_b) { v2.load(b); b += sb; }
+            if (ld_c) { v3.load(cc); cc += s_c; }
+            row(v1, v2, v3);
         }
     }
     // block reduction over the TY row lanes through LDS, then ONE atomic per (channel, statistic)
@@ -175,7 +259,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
         if (NS == 2) red[(1 * ty + ly) * row_w + lx * VEC + e] = s2[e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NS * row_w; i += 256) {
+    for (int i = threadIdx.x; i < NS * row_w; i += (int)blockDim.x) {
         const int st = i / row_w;  // 0 or 1 (uniform per 256-thread pass when row_w >= 256, cheap otherwise)
         const int col = i - st * row_w;
         float acc = 0.f;
@@ -193,11 +277,29 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
 template <int MODE>
 int launch_colreduce(int dtype, RedParams P, int groups, hipStream_t st, const char* who) {
     static const int k_rows = env_int("BGAMD_RED_ROWS", 16), k_blocks = env_int("BGAMD_RED_BLOCKS", 1024);  // tuning knobs
+    // the power-of-two channel tiling only: with whole rows per block every block would fold and add ALL channels
+    // (measured: 31 -> 52 us on the 40 MB tensors)
     const Tiling t = make_tiling(dtype, P.C, P.rows_per_group, groups, k_rows, k_blocks);
-    P.tx = t.tx; P.log_tx = t.log_tx; P.rows_per_block = t.rows_per_block; P.gx = t.gx; P.gy = t.gy;
+    P.tx = t.tx; P.ty = t.ty; P.rows_per_block = t.rows_per_block; P.gx = t.gx; P.gy = t.gy;
     BG_CHECK_ARG(groups <= 65535, "%s: too many groups", who);
     dim3 grid(xcd_grid(t.gx, t.gy), 1, (unsigned)groups);
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, st, P));
+    const dim3 block(t.tx * t.ty);
+    if (MODE != RED_BWD) {
+        BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colreduce_kernel<T, MODE, 0, false>), grid, block, 0, st, P));
+    } else {
+        const int sign = !P.act ? 0 : (P.b ? 1 : 2);
+#define BG_RED_BWD(S, X) BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colreduce_kernel<T, RED_BWD, S, X>), grid, block, 0, st, P))
+        if (P.c) {
+            if (sign == 0) BG_RED_BWD(0, true);
+            else if (sign == 1) BG_RED_BWD(1, true);
+            else BG_RED_BWD(2, true);
+        } else {
+            BG_CHECK_ARG(sign != 2, "%s: the recomputed activation branch needs x", who);
+            if (sign == 0) BG_RED_BWD(0, false);
+            else BG_RED_BWD(1, false);
+        }
+#undef BG_RED_BWD
+    }
     BG_CHECK_LAUNCH(who);
     return BG_OK;
 }
@@ -269,12 +371,14 @@ __global__ void norm_bwd_finalize_kernel(const double* s1, const double* s2, lon
 }
 
 // ------------------------------------------------------------ element-wise --
+constexpr int EW_U = 4;  // rows in flight per thread (16 B each per operand)
+
 struct EwParams {
     const void* x; int ldx;
     const float* scale; const float* shift;
     const void* res; int ldres;
     void* y; int ldy;
-    int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
+    int C; long long rows_per_group; int rows_per_block; int act; int tx, ty;
     // fused finalize (training-mode statistics -> affine) when sum != NULL
     const double* sum; const double* sumsq;
     const float* gamma; const float* beta;
@@ -284,84 +388,140 @@ struct EwParams {
     int gx, gy;
 };
 
-template <typename T>
+template <typename T, bool RES>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     constexpr int VEC = Elem<T>::VEC;
-    const int lx = threadIdx.x & (P.tx - 1);
-    const int ly = threadIdx.x >> P.log_tx;
-    const int ty = 256 >> P.log_tx;
+    const int ly = (int)threadIdx.x / P.tx;
+    const int lx = (int)threadIdx.x - ly * P.tx;
+    const int ty = P.ty;
     BG_BLOCK_COORDS(P, bx, by);
     const int c = (bx * P.tx + lx) * VEC;
-    if (c >= P.C) return;
     const int g = blockIdx.z;
     const long long r0 = (long long)by * P.rows_per_block;
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
-    float sc[VEC], sh[VEC];
-    if (P.sum) {
-        // every thread derives the affine of its own channels from the fp64 sums (a few flops);
-        // the first row-block of each group also publishes mean / rstd for the backward pass
-        // and applies the BatchNorm running-statistics update -- no separate finalize launch
-        const bool publish = by == 0 && ly == 0;
+    // Per-channel affine: the block derives it ONCE per channel, lanes along channels (coalesced table reads), and
+    // hands it to the row lanes through LDS.  When every thread read its own 8 channels straight from the tables, each
+    // wave-level load touched 32-64 cache lines for 4-8 useful bytes per lane: rocprofv3 counted 8x the L1 accesses of
+    // a plain copy of the same tensor and the kernel ran 1.5x slower than that copy (scripts/ew_patterns.hip).
+    extern __shared__ float ew_tab[];
+    const int row_w = P.tx * VEC, nthr = P.tx * ty;
+    float* s_sc = ew_tab;
+    float* s_sh = ew_tab + row_w;
+    {
         const double n = (double)P.rows_per_group;
         const double inv_n = 1.0 / n;  // one fp64 division per thread; the rest is fp64 mul/add + one fp32 rsqrt
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const long long i = (long long)g * P.C + c + e;
-            const double m = P.sum[i] * inv_n;
-            double var = P.sumsq[i] * inv_n - m * m;  // the cancellation-prone step stays in fp64
-            if (var < 0.0 || P.rows_per_group == 1) var = 0.0;
-            const float r = rsqrtf((float)var + P.eps);
-            const float gm = P.gamma ? P.gamma[c + e] : 1.f;
-            const float bt = P.beta ? P.beta[c + e] : 0.f;
-            norm_affine(gm, bt, (float)m, r, sc[e], sh[e]);
-            if (publish) {
-                P.mean_out[i] = (float)m;
-                P.rstd_out[i] = r;
-                if (P.rmean && g == 0) {
-                    // BatchNorm over several statistic groups (sub-batches the reference pushes through the
-                    // layer in separate calls): one momentum update per group, in group order
-                    float rm = P.rmean[c + e], rv = P.rvar[c + e];
-                    for (int gg = 0; gg < (int)gridDim.z; ++gg) {
-                        const long long j = (long long)gg * P.C + c + e;
-                        const double mg = P.sum[j] * inv_n;
-                        double vg = P.sumsq[j] * inv_n - mg * mg;
-                        if (vg < 0.0 || P.rows_per_group == 1) vg = 0.0;
-                        const double unb = P.rows_per_group > 1 ? vg * n / (n - 1.0) : vg;
-                        rm = (1.f - P.momentum) * rm + P.momentum * (float)mg;
-                        rv = (1.f - P.momentum) * rv + P.momentum * (float)unb;
+        for (int ch = threadIdx.x; ch < row_w; ch += nthr) {
+            const int cg = bx * row_w + ch;
+            float a = 1.f, b = 0.f;
+            if (cg < P.C) {
+                const long long i = (long long)g * P.C + cg;
+                if (P.sum) {
+                    // fused finalize: the affine from the fp64 sums; the first row-block of each group also publishes
+                    // mean / rstd for the backward pass and applies the BatchNorm running-statistics update
+                    const double m = P.sum[i] * inv_n;
+                    double var = P.sumsq[i] * inv_n - m * m;  // the cancellation-prone step stays in fp64
+                    if (var < 0.0 || P.rows_per_group == 1) var = 0.0;
+                    const float r = rsqrtf((float)var + P.eps);
+                    norm_affine(P.gamma ? P.gamma[cg] : 1.f, P.beta ? P.beta[cg] : 0.f, (float)m, r, a, b);
+                    if (by == 0) {
+                        P.mean_out[i] = (float)m;
+                        P.rstd_out[i] = r;
+                        if (P.rmean && g == 0) {
+                            // BatchNorm over several statistic groups (sub-batches the reference pushes through the
+                            // layer in separate calls): one momentum update per group, in group order
+                            float rm = P.rmean[cg], rv = P.rvar[cg];
+                            for (int gg = 0; gg < (int)gridDim.z; ++gg) {
+                                const long long j = (long long)gg * P.C + cg;
+                                const double mg = P.sum[j] * inv_n;
+                                double vg = P.sumsq[j] * inv_n - mg * mg;
+                                if (vg < 0.0 || P.rows_per_group == 1) vg = 0.0;
+                                const double unb = P.rows_per_group > 1 ? vg * n / (n - 1.0) : vg;
+                                rm = (1.f - P.momentum) * rm + P.momentum * (float)mg;
+                                rv = (1.f - P.momentum) * rv + P.momentum * (float)unb;
+                            }
+                            P.rmean[cg] = rm;
+                            P.rvar[cg] = rv;
+                        }
                     }
-                    P.rmean[c + e] = rm;
-                    P.rvar[c + e] = rv;
+                } else if (P.scale) {
+                    a = P.scale[i];
+                    b = P.shift[i];
                 }
             }
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            sc[e] = P.scale ? P.scale[(long long)g * P.C + c + e] : 1.f;
-            sh[e] = P.scale ? P.shift[(long long)g * P.C + c + e] : 0.f;
+            s_sc[ch] = a;
+            s_sh[ch] = b;
         }
     }
+    __syncthreads();
+    if (c >= P.C) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = s_sc[lx * VEC + e];
+        sh[e] = s_sh[lx * VEC + e];
+    }
     const T* x = reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c;
-    const T* res = P.res ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
+    const T* res = RES ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
     T* y = reinterpret_cast<T*>(P.y) + row0 * P.ldy + c;
     const long long sx = (long long)ty * P.ldx, sr = (long long)ty * P.ldres, sy = (long long)ty * P.ldy;
-#pragma unroll 4
-    for (long long r = r0 + ly; r < r1; r += ty) {
-        Chunk<T> vx, vr, vo;
-        vx.load(x);
-        x += sx;
-        if (res) { vr.load(res); res += sr; }
+    // LeakyReLU / ReLU / identity as max(z, slope*z) with slope 0.2 / 0 / 1: the same values as the branch
+    // (z >= 0 ? z : slope*z) for every slope in [0, 1], with no per-element selects on run-time flags.  These kernels
+    // are HBM-bound only while the VALU work per 16-byte chunk stays small: with the act / residual flags tested per
+    // element the bf16 kernel spent ~85 VALU instructions per chunk and ran 1.5x slower than a copy.
+    const float slope = act_max_slope(P.act);
+    auto row = [&](const Chunk<T>& vx, const Chunk<T>& vr, T* out) {
+        Chunk<T> vo;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float z = fmaf(vx.get(e), sc[e], sh[e]);
-            if (res) z += vr.get(e);
-            if (P.act) z = z >= 0.f ? z : act_slope(P.act) * z;
-            vo.set(e, z);
+            if (RES) z += vr.get(e);
+            vo.set(e, fmaxf(z, slope * z));
         }
-        vo.store(y);
+        vo.store(out);
+    };
+    // EW_U rows per thread are in flight before the first is used, and the next batch is requested before the current
+    // one is computed and stored (the one-row "#pragma unroll 4" loop compiled to load -> s_waitcnt vmcnt(0) -> store).
+    long long r = r0 + ly;
+    const long long step = EW_U * (long long)ty;
+    Chunk<T> vx[EW_U], vr[EW_U];
+    bool have = r + step - ty < r1;
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            vx[u].load(x + u * sx);
+            if (RES) vr[u].load(res + u * sr);
+        }
+    }
+    while (have) {
+        Chunk<T> cx[EW_U], cr[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            cx[u] = vx[u];
+            if (RES) cr[u] = vr[u];
+        }
+        r += step;
+        x += EW_U * sx;
+        if (RES) res += EW_U * sr;
+        have = r + step - ty < r1;
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                vx[u].load(x + u * sx);
+                if (RES) vr[u].load(res + u * sr);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) row(cx[u], cr[u], y + u * sy);
+        y += EW_U * sy;
+    }
+    for (; r < r1; r += ty) {
+        Chunk<T> v1, v2;
+        v1.load(x);
+        x += sx;
+        if (RES) { v2.load(res); res += sr; }
+        row(v1, v2, y);
         y += sy;
     }
 }
@@ -373,7 +533,7 @@ struct EwBwdParams {
     const float* A; const float* B; const float* Cc;
     void* dx; int lddx;
     void* dres; int lddres;
-    int C; long long rows_per_group; int rows_per_block; int act; int tx, log_tx;
+    int C; long long rows_per_group; int rows_per_block; int act; int tx, ty;
     // fused finalize when s1 != NULL: coefficients from the fp64 sums, dgamma/dbeta by the first row-block
     const double* s1; const double* s2;
     const float* gamma; const float* beta; const float* mean; const float* rstd;
@@ -382,98 +542,187 @@ struct EwBwdParams {
     int gx, gy;
 };
 
-template <typename T>
+// SIGN: where the activation's branch comes from (0 no activation, 1 the stored output y, 2 recomputed from
+// x*scale+shift); DRES: also write the residual branch's gradient; USEB: training-mode statistics terms (needs x).
+// Compile-time so that the per-element code carries no selects on run-time flags (see norm_act_fwd_kernel).
+template <typename T, int SIGN, bool DRES, bool USEB>
 __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) {
     constexpr int VEC = Elem<T>::VEC;
-    const int lx = threadIdx.x & (P.tx - 1);
-    const int ly = threadIdx.x >> P.log_tx;
-    const int ty = 256 >> P.log_tx;
+    const int ly = (int)threadIdx.x / P.tx;
+    const int lx = (int)threadIdx.x - ly * P.tx;
+    const int ty = P.ty;
     BG_BLOCK_COORDS(P, bx, by);
     const int c = (bx * P.tx + lx) * VEC;
-    if (c >= P.C) return;
     const int g = blockIdx.z;
     const long long r0 = (long long)by * P.rows_per_block;
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
-    const bool useB = P.s1 ? (P.train != 0) : (P.A && P.B);
-    float ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
-    const bool sign_from_x = P.act && !P.y;  // no residual: the LeakyReLU branch follows from x*scale+shift
-    if (P.s1) {
+    constexpr bool useB = USEB;
+    // per-channel coefficients once per block, lanes along channels, handed over through LDS (see norm_act_fwd_kernel)
+    extern __shared__ float ew_tab[];
+    const int row_w = P.tx * VEC, nthr = P.tx * ty;
+    {
         const float inv_n = 1.f / (float)P.rows_per_group;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const long long i = (long long)g * P.C + c + e;
-            const float gm = P.gamma ? P.gamma[c + e] : 1.f;
-            const float r = P.rstd[i], m = P.mean[i];
-            norm_affine(gm, P.beta ? P.beta[c + e] : 0.f, m, r, sc[e], sh[e]);
-            const float a1 = (float)P.s1[i] * inv_n, a2 = (float)P.s2[i] * inv_n;  // means of g and g*xhat
-            ca[e] = gm * r;
-            cb[e] = P.train ? -gm * r * r * a2 : 0.f;
-            cc[e] = P.train ? gm * r * (r * a2 * m - a1) : 0.f;
-        }
-        if (P.dgamma && by == 0 && ly == 0 && g == 0) {
-            // parameter gradients: sum over groups (one thread per channel, once)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                double t1 = 0.0, t2 = 0.0;
-                for (int gg = 0; gg < P.groups; ++gg) {
-                    t1 += P.s1[(long long)gg * P.C + c + e];
-                    t2 += P.s2[(long long)gg * P.C + c + e];
+        for (int ch = threadIdx.x; ch < row_w; ch += nthr) {
+            const int cg = bx * row_w + ch;
+            float a = 1.f, b = 0.f, cc0 = 0.f, s = 1.f, h = 0.f;
+            if (cg < P.C) {
+                const long long i = (long long)g * P.C + cg;
+                if (P.s1) {
+                    // fused finalize: coefficients from the fp64 sums; dgamma / dbeta by the first row-block
+                    const float gm = P.gamma ? P.gamma[cg] : 1.f;
+                    const float r = P.rstd[i], m = P.mean[i];
+                    norm_affine(gm, P.beta ? P.beta[cg] : 0.f, m, r, s, h);
+                    const float a1 = (float)P.s1[i] * inv_n, a2 = (float)P.s2[i] * inv_n;  // means of g and g*xhat
+                    a = gm * r;
+                    b = P.train ? -gm * r * r * a2 : 0.f;
+                    cc0 = P.train ? gm * r * (r * a2 * m - a1) : 0.f;
+                    if (P.dgamma && by == 0 && g == 0) {
+                        // parameter gradients: sum over groups (one thread per channel, once)
+                        double t1 = 0.0, t2 = 0.0;
+                        for (int gg = 0; gg < P.groups; ++gg) {
+                            t1 += P.s1[(long long)gg * P.C + cg];
+                            t2 += P.s2[(long long)gg * P.C + cg];
+                        }
+                        P.dgamma[cg] += (float)t2;
+                        P.dbeta[cg] += (float)t1;
+                    }
+                } else {
+                    a = P.A ? P.A[i] : 1.f;
+                    b = useB ? P.B[i] : 0.f;
+                    cc0 = useB ? P.Cc[i] : 0.f;
                 }
-                P.dgamma[c + e] += (float)t2;
-                P.dbeta[c + e] += (float)t1;
             }
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const long long so = (long long)g * P.C + c + e;
-            sc[e] = 1.f;
-            sh[e] = 0.f;
-            ca[e] = P.A ? P.A[so] : 1.f;
-            cb[e] = useB ? P.B[so] : 0.f;
-            cc[e] = useB ? P.Cc[so] : 0.f;
+            ew_tab[ch] = a;
+            ew_tab[row_w + ch] = b;
+            ew_tab[2 * row_w + ch] = cc0;
+            ew_tab[3 * row_w + ch] = s;
+            ew_tab[4 * row_w + ch] = h;
         }
     }
+    __syncthreads();
+    if (c >= P.C) return;
+    float ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        ca[e] = ew_tab[lx * VEC + e];
+        cb[e] = ew_tab[row_w + lx * VEC + e];
+        cc[e] = ew_tab[2 * row_w + lx * VEC + e];
+        sc[e] = ew_tab[3 * row_w + lx * VEC + e];
+        sh[e] = ew_tab[4 * row_w + lx * VEC + e];
+    }
+    constexpr bool LDX = USEB || SIGN == 2;
     const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;
-    const T* y = (P.act && P.y) ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
-    const bool scaleA = P.s1 || P.A;
-    const T* x = (useB || sign_from_x) ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
+    const T* y = SIGN == 1 ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
+    const T* x = LDX ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
     T* dx = P.dx ? reinterpret_cast<T*>(P.dx) + row0 * P.lddx + c : nullptr;
-    T* dres = P.dres ? reinterpret_cast<T*>(P.dres) + row0 * P.lddres + c : nullptr;
+    T* dres = DRES ? reinterpret_cast<T*>(P.dres) + row0 * P.lddres + c : nullptr;
     const long long s_dy = (long long)ty * P.lddy, s_y = (long long)ty * P.ldy, s_x = (long long)ty * P.ldx;
     const long long s_dx = (long long)ty * P.lddx, s_dr = (long long)ty * P.lddres;
-#pragma unroll 4
-    for (long long r = r0 + ly; r < r1; r += ty) {
-        Chunk<T> vg, vy, vx, vo;
-        vg.load(dy);
-        dy += s_dy;
-        if (y) { vy.load(y); y += s_y; }
-        if (x) { vx.load(x); x += s_x; }
+    const float slope = act_slope(P.act);
+    auto row = [&](const Chunk<T>& vg, const Chunk<T>& vy, const Chunk<T>& vx, T* o_res, T* o_dx) {
+        Chunk<T> vo;
         float gg[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             gg[e] = vg.get(e);
-            if (P.act) gg[e] *= ((y ? vy.get(e) : fmaf(vx.get(e), sc[e], sh[e])) > 0.f ? 1.f : act_slope(P.act));
+            if (SIGN == 1) gg[e] *= vy.get(e) > 0.f ? 1.f : slope;
+            if (SIGN == 2) gg[e] *= fmaf(vx.get(e), sc[e], sh[e]) > 0.f ? 1.f : slope;
         }
-        if (dres) {
+        if (DRES) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) vo.set(e, gg[e]);
-            vo.store(dres);
-            dres += s_dr;
+            vo.store(o_res);
         }
         if (dx) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float d = scaleA ? gg[e] * ca[e] : gg[e];
+                float d = gg[e] * ca[e];
                 if (useB) d += fmaf(cb[e], vx.get(e), cc[e]);
                 vo.set(e, d);
             }
-            vo.store(dx);
-            dx += s_dx;
+            vo.store(o_dx);
         }
+    };
+    auto load = [&](Chunk<T>* vg, Chunk<T>* vy, Chunk<T>* vx) {
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            vg[u].load(dy + u * s_dy);
+            if (SIGN == 1) vy[u].load(y + u * s_y);
+            if (LDX) vx[u].load(x + u * s_x);
+        }
+    };
+    // software-pipelined batches of EW_U rows (see norm_act_fwd_kernel)
+    long long r = r0 + ly;
+    const long long step = EW_U * (long long)ty;
+    Chunk<T> vg[EW_U], vy[EW_U], vx[EW_U];
+    bool have = r + step - ty < r1;
+    if (have) load(vg, vy, vx);
+    while (have) {
+        Chunk<T> cg[EW_U], cy[EW_U], cx[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            cg[u] = vg[u];
+            if (SIGN == 1) cy[u] = vy[u];
+            if (LDX) cx[u] = vx[u];
+        }
+        r += step;
+        dy += EW_U * s_dy;
+        if (SIGN == 1) y += EW_U * s_y;
+        if (LDX) x += EW_U * s_x;
+        have = r + step - ty < r1;
+        if (have) load(vg, vy, vx);
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) row(cg[u], cy[u], cx[u], dres + u * s_dr, dx + u * s_dx);
+        if (DRES) dres += EW_U * s_dr;
+        if (dx) dx += EW_U * s_dx;
     }
+    for (; r < r1; r += ty) {
+        Chunk<T> v1, v2, v3;
+        v1.load(dy);
+        dy += s_dy;
+        if (SIGN == 1) { v2.load(y); y += s_y; }
+        if (LDX) { v3.load(x); x += s_x; }
+        row(v1, v2, v3, dres, dx);
+        if (DRES) dres += s_dr;
+        if (dx) dx += s_dx;
+    }
+}
+
+template <typename T, int SIGN>
+void launch_bwd_apply_s(const EwBwdParams& P, const dim3 grid, const dim3 block, bool useB, hipStream_t st) {
+    const size_t lds = (size_t)5 * P.tx * Elem<T>::VEC * sizeof(float);
+    if (P.dres) {
+        if (useB) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, true, true>), grid, block, lds, st, P);
+        else hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, true, false>), grid, block, lds, st, P);
+    } else {
+        if (useB) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, false, true>), grid, block, lds, st, P);
+        else hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, false, false>), grid, block, lds, st, P);
+    }
+}
+template <typename T>
+void launch_bwd_apply_t(const EwBwdParams& P, const Tiling& t, int groups, hipStream_t st) {
+    const dim3 grid(xcd_grid(t.gx, t.gy), 1, groups), block(t.tx * t.ty);
+    const bool useB = P.s1 ? (P.train != 0) : (P.A && P.B);
+    const int sign = !P.act ? 0 : (P.y ? 1 : 2);
+    if (sign == 0) launch_bwd_apply_s<T, 0>(P, grid, block, useB, st);
+    else if (sign == 1) launch_bwd_apply_s<T, 1>(P, grid, block, useB, st);
+    else launch_bwd_apply_s<T, 2>(P, grid, block, useB, st);
+}
+inline void launch_bwd_apply(int dtype, const EwBwdParams& P, const Tiling& t, int groups, hipStream_t st) {
+    BG_DISPATCH_DTYPE(dtype, T, launch_bwd_apply_t<T>(P, t, groups, st));
+}
+
+template <typename T>
+void launch_norm_act_fwd_t(const EwParams& P, const Tiling& t, int groups, hipStream_t st) {
+    const dim3 grid(xcd_grid(t.gx, t.gy), 1, groups), block(t.tx * t.ty);
+    const size_t lds = (size_t)2 * t.tx * Elem<T>::VEC * sizeof(float);
+    if (P.res) hipLaunchKernelGGL((norm_act_fwd_kernel<T, true>), grid, block, lds, st, P);
+    else hipLaunchKernelGGL((norm_act_fwd_kernel<T, false>), grid, block, lds, st, P);
+}
+inline void launch_norm_act_fwd(int dtype, const EwParams& P, const Tiling& t, int groups, hipStream_t st) {
+    BG_DISPATCH_DTYPE(dtype, T, launch_norm_act_fwd_t<T>(P, t, groups, st));
 }
 
 inline unsigned ew_grid(long long total) {
@@ -591,13 +840,12 @@ extern "C" int bg_norm_act_fwd(int32_t dtype, const void* x, int32_t ldx, const 
         BG_CHECK_ARG(aligned16(res), "bg_norm_act_fwd: unaligned res");
         CHECK_LD(ldres, "bg_norm_act_fwd");
     }
-    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192, common_ld({ldx, ldy, res ? ldres : 0}));
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd: too many groups");
-    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
+    EwParams P{x, ldx, scale, shift, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.ty,
                nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
     P.gx = t.gx; P.gy = t.gy;
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
-                                                   (hipStream_t)stream, P));
+    launch_norm_act_fwd(dtype, P, t, groups, (hipStream_t)stream);
     BG_CHECK_LAUNCH("norm_act_fwd_kernel");
     return BG_OK;
 }
@@ -627,13 +875,13 @@ extern "C" int bg_norm_act_bwd_apply(int32_t dtype, const void* dy, int32_t lddy
         BG_CHECK_ARG(aligned16(dres), "bg_norm_act_bwd_apply: unaligned dres");
         CHECK_LD(lddres, "bg_norm_act_bwd_apply");
     }
-    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192);
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, 4, 8192,
+                                 common_ld({lddy, (act && y) ? ldy : 0, (A && B) ? ldx : 0, dx ? lddx : 0, dres ? lddres : 0}));
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply: too many groups");
     EwBwdParams P{dy, lddy, y, ldy, x, ldx, A, B, Cc, dx, lddx, dres, lddres, C, rows / groups, t.rows_per_block, act,
-                  t.tx, t.log_tx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, groups};
+                  t.tx, t.ty, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, groups};
     P.gx = t.gx; P.gy = t.gy;
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
-                                                   (hipStream_t)stream, P));
+    launch_bwd_apply(dtype, P, t, groups, (hipStream_t)stream);
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel");
     return BG_OK;
 }
@@ -658,13 +906,12 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
     // fewer, longer-running threads than the plain apply kernel: each thread first derives its
     // channels' affine from the sums, which must be amortised over the rows it then walks
     static const int k_rows = env_int("BGAMD_EWS_ROWS", 16), k_blocks = env_int("BGAMD_EWS_BLOCKS", 1024);  // tuning knobs
-    const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks);
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks, common_ld({ldx, ldy, res ? ldres : 0}));
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd_stats: too many groups");
-    EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.log_tx,
+    EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.ty,
                sum, sumsq, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd};
     P.gx = t.gx; P.gy = t.gy;
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_fwd_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
-                                                   (hipStream_t)stream, P));
+    launch_norm_act_fwd(dtype, P, t, groups, (hipStream_t)stream);
     BG_CHECK_LAUNCH("norm_act_fwd_kernel(stats)");
     return BG_OK;
 }
@@ -696,13 +943,13 @@ extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_
         CHECK_LD(lddres, "bg_norm_act_bwd_apply_stats");
     }
     static const int k_rows = env_int("BGAMD_EWS_ROWS", 16), k_blocks = env_int("BGAMD_EWS_BLOCKS", 1024);  // tuning knobs
-    const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks);
+    const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks,
+                                 common_ld({lddy, y ? ldy : 0, ldx, dx ? lddx : 0, dres ? lddres : 0}));
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply_stats: too many groups");
     EwBwdParams P{dy, lddy, y, ldy, x, ldx, nullptr, nullptr, nullptr, dx, lddx, dres, lddres, C, rows / groups,
-                  t.rows_per_block, act, t.tx, t.log_tx, s1, s2, gamma, beta, mean, rstd, dgamma, dbeta, train, groups};
+                  t.rows_per_block, act, t.tx, t.ty, s1, s2, gamma, beta, mean, rstd, dgamma, dbeta, train, groups};
     P.gx = t.gx; P.gy = t.gy;
-    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T>), dim3(xcd_grid(t.gx, t.gy), 1, groups), dim3(256), 0,
-                                                   (hipStream_t)stream, P));
+    launch_bwd_apply(dtype, P, t, groups, (hipStream_t)stream);
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel(stats)");
     return BG_OK;
 }

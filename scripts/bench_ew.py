@@ -58,6 +58,17 @@ def main():
                    beta.data_ptr(), 1e-5, 0.1, None, None, mean.data_ptr(), rstd.data_ptr(), None, 0, ys[i].data_ptr(), cp,
                    rows, cp, 1, 1)
 
+        scale, shift = torch.rand(cp, device=DEV) + 0.5, torch.randn(cp, device=DEV) * 0.1
+
+        def fwd_plain():
+            i = nxt()
+            L.call("bg_norm_act_fwd", dt, xs[i].data_ptr(), cp, scale.data_ptr(), shift.data_ptr(), None, 0, ys[i].data_ptr(), cp,
+                   rows, cp, 1, 1)
+
+        def finalize():
+            L.call("bg_norm_finalize", s.data_ptr(), ss.data_ptr(), rows, 1, cp, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None,
+                   mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+
         def stats():
             i = nxt()
             L.call("bg_norm_stats", dt, xs[i].data_ptr(), rows, cp, cp, 1, s1.data_ptr(), s2.data_ptr())
@@ -91,7 +102,8 @@ def main():
             i = nxt()
             ys[i].copy_(xs[i])
 
-        cases = [("copy(torch)", copy, 2), ("norm_stats", stats, 1), ("norm_act_fwd_stats", fwd_stats, 2),
+        cases = [("copy(torch)", copy, 2), ("norm_stats", stats, 1), ("norm_act_fwd_stats", fwd_stats, 2), ("norm_act_fwd(plain)", fwd_plain, 2),
+                 ("norm_finalize", finalize, 0),
                  ("bwd_reduce", bwd_reduce, 2), ("bwd_apply_stats", bwd_apply, 3), ("dw_fwd", dw_fwd, 2),
                  ("dw_bwd_data", dw_bwd_data, 2), ("dw_bwd_weight", dw_bwd_weight, 2)]
         for name, fn, k in cases:
