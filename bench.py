@@ -328,15 +328,30 @@ def main():
         batches = [feed.next(), feed.next()]
     # ---- roofline: one extra (un-timed) step with HIP events around every C-ABI launch
     # (every rank runs the step -- it contains the gradient all-reduces -- rank 0 records)
+    # Two such steps, every launch keeps the shorter of its two measurements: a bracket also contains whatever the host
+    # did between recording the first event and launching (an allocator trim, a page fault), which once put 25 ms on a
+    # 1 ms kernel and moved the whole family's figure.
+    prof = []
     if not args.no_kernel_profile:
-        if rank == 0:
-            L.PROFILE = []
         side, trainer._side = trainer._side, None   # one stream for this step: events then bracket ONE kernel each
-        trainer.step(*batches[0])
-        torch.cuda.synchronize()
+        for _ in range(2):
+            if rank == 0:
+                L.PROFILE = []
+            trainer.step(*batches[0])
+            torch.cuda.synchronize()
+            if rank == 0:
+                prof.append([(nm, fl, e0.elapsed_time(e1), nb) for nm, fl, e0, e1, nb in L.PROFILE])
+                L.PROFILE = None
         trainer._side = side
     if rank == 0 and not args.no_kernel_profile:
-        recs, L.PROFILE = L.PROFILE, None
+        a, b = prof
+        if len(a) == len(b) and all(x[0] == y[0] for x, y in zip(a, b)):
+            a = [(x[0], x[1], min(x[2], y[2]), x[3]) for x, y in zip(a, b)]
+
+        class _Ev:   # (elapsed already taken)
+            def __init__(self, ms): self.ms = ms
+            def elapsed_time(self, other): return other.ms
+        recs = [(nm, fl, _Ev(0.0), _Ev(ms), nb) for nm, fl, ms, nb in a]
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
                 for name, flops, e0, e1, nbytes in recs:

@@ -135,10 +135,33 @@ import os as _os
 _FUSED_STATS = _os.environ.get("BGAMD_NO_FUSED_STATS") is None  # A/B switch
 
 
-def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
+_FUSED_DW = _os.environ.get("BGAMD_NO_FUSED_DW") is None  # A/B switch: BatchNorm + LeakyReLU inside the next depthwise conv
+
+
+def norm_dw_fusable(m: nn.Module, nxt) -> bool:
+    """[norm m -> LeakyReLU -> SeparableConv2d_same nxt]: can the depthwise kernel of `nxt` apply m's affine and the
+    activation to its input itself (ops.NormActDwConvFn)?  Training-mode BatchNorm2d, stride 1, dilation 1 or 2."""
+    return (_FUSED_DW and isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats
+            and isinstance(nxt, SeparableConv2d_same) and nxt.conv1.stride[0] == 1 and nxt.conv1.dilation[0] in (1, 2))
+
+
+def norm_act_dw(owner: BGModule, m: nn.BatchNorm2d, x, stats, dw: "Conv2d"):
+    """dw( LeakyReLU( m(x) ) ) in one pass over x (see norm_dw_fusable)."""
+    a = owner.arena()
+    groups = ops.current_bn_groups()
+    m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + groups
+    mom = 0.1 if m.momentum is None else float(m.momentum)
+    return ops.NormActDwConvFn.apply(x, m.weight, m.bias, dw.weight, a, a.by_param[id(m.weight)], a.by_param[id(m.bias)],
+                                     a.by_param[id(dw.weight)], m.running_mean, m.running_var, True, float(m.eps), mom,
+                                     stats, groups, dw.dilation[0])
+
+
+def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False, skip_dw=False, defer_norm=False):
     """conv (Conv2d or SeparableConv2d_same) -> norm (+ residual) (+ LeakyReLU).  When the
     normaliser is a training-mode BatchNorm2d its batch statistics come out of the
-    convolution's epilogue instead of a separate pass over the conv output."""
+    convolution's epilogue instead of a separate pass over the conv output.
+    skip_dw: x is already the depthwise output of `conv` (norm_act_dw ran it); defer_norm: return
+    (raw conv output, its statistics) for norm_act_dw instead of applying the norm."""
     dense = conv.pointwise if isinstance(conv, SeparableConv2d_same) else conv
     stats = None
     if isinstance(m, nn.BatchNorm2d) and m.training and dense.bias is None and _FUSED_STATS:
@@ -154,7 +177,12 @@ def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False):
         if groups == 1 or (n % groups == 0 and (n // groups * ho * wo) % 128 == 0):
             kp = owner.arena().by_param[id(dense.weight)].phys_shape[0]
             stats = StatsPool.get(x.device).take(2, groups, kp)
-    y = conv(x, stats) if stats is not None else conv(x)
+    if skip_dw:
+        y = conv.pointwise(x, stats)
+    else:
+        y = conv(x, stats) if stats is not None else conv(x)
+    if defer_norm:
+        return y, stats
     return apply_norm(owner, m, y, res=res, act=act, stats=stats)
 
 
@@ -244,12 +272,14 @@ class Block(BGModule):
         h = a_main
         last_norm = None
         last_sep = None
+        dw_done = False  # h is already the depthwise output of the unit about to run (norm_act_dw)
         while i < len(units):
             u = units[i]
             if isinstance(u, SeparableConv2d_same):
                 nxt_norm = i + 1 < len(units) and not isinstance(units[i + 1], (SeparableConv2d_same, nn.LeakyReLU))
                 if not nxt_norm:
-                    h = u(h)
+                    h = u.pointwise(h) if dw_done else u(h)
+                    dw_done = False
                     i += 1
                     continue
                 m = units[i + 1]
@@ -257,7 +287,15 @@ class Block(BGModule):
                     last_norm, last_sep = m, u
                     break
                 nxt_relu = isinstance(units[i + 2], nn.LeakyReLU)
-                h = conv_norm(self, u, m, h, act=nxt_relu)
+                if nxt_relu and i + 3 < len(units) and norm_dw_fusable(m, units[i + 3]):
+                    # [u -> m -> LeakyReLU -> next unit]: m and the activation run inside the next unit's depthwise kernel
+                    z, stats = conv_norm(self, u, m, h, skip_dw=dw_done, defer_norm=True)
+                    h = norm_act_dw(self, m, z, stats, units[i + 3].conv1)
+                    dw_done = True
+                    i += 3
+                    continue
+                h = conv_norm(self, u, m, h, act=nxt_relu, skip_dw=dw_done)
+                dw_done = False
                 i += 3 if nxt_relu else 2
             elif isinstance(u, nn.LeakyReLU):
                 h = ops.leaky_relu(h)
@@ -270,7 +308,7 @@ class Block(BGModule):
         else:
             s = a_skip
         if last_norm is not None:
-            return conv_norm(self, last_sep, last_norm, h, res=s, act=activate_output)
+            return conv_norm(self, last_sep, last_norm, h, res=s, act=activate_output, skip_dw=dw_done)
         return ops.add(h, s, act=activate_output)
 
 

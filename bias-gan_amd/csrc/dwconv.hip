@@ -16,7 +16,29 @@ struct DwParams {
     int bx;     // 256-thread blocks per image row; the grid is 1-D: rows * bx blocks
     int rb, bands;  // dw_s1_kernel: output rows per band, bands per image
     int wgroups, bands_per_phase;  // ... per column phase / row phase (dilation D: D phases each way)
+    // PRE = 1 (dw_s1_kernel): the input is a raw convolution output; the normalisation's affine and the activation
+    // are applied to every loaded chunk (x -> act(x*scale + shift), out-of-image taps stay zero)
+    const float* pre_scale;  // [groups, C]
+    const float* pre_shift;
+    int pre_act;
+    int pre_ipg;  // images per statistic group
 };
+
+// Normalisation + activation of one loaded chunk, rounded to T exactly as bg_norm_act_fwd would have stored it (the
+// fused and the unfused pipelines give identical bits).  keep = false: the tap lies outside the image ("same" zero
+// padding applies to the ACTIVATED tensor, so an out-of-range load's zero must stay zero).
+template <typename T>
+__device__ __forceinline__ void dw_pre_apply(Chunk<T>& v, const float* sc, const float* sh, float slope, bool keep) {
+    constexpr int VEC = Elem<T>::VEC;
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float z = fmaf(v.get(e), sc[e], sh[e]);
+        o.set(e, fmaxf(z, slope * z));
+    }
+    if (!keep) o.zero();
+    v = o;
+}
 
 // 1-D grid -> (image row, block inside the row).  Blocks with the same id % 8 share an
 // XCD and its L2; give every XCD a CONTIGUOUS band of rows, so the three output rows
@@ -141,7 +163,7 @@ __global__ __launch_bounds__(256) void dw_fwd_tw_kernel(DwParams P) {
 // row is fetched while the current one is being used.  FLIP = 1 reverses the taps (data gradient).
 // Dilation D (exit flow, D = 2) is the same kernel on the D x D sub-lattices of the image: a thread's
 // four output columns and the rows it walks are D apart, so its window is again 3 rows x 6 columns.
-template <typename T, int FLIP>
+template <typename T, int FLIP, int PRE>
 __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int TW = 4, NCOL = TW + 2;
@@ -178,10 +200,38 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
     };
+    float psc[VEC], psh[VEC];
+    bool cok[NCOL];
+    const float pslope = act_max_slope(P.pre_act);
+    if (PRE) {
+        const long long o = (long long)(n / P.pre_ipg) * P.C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(P.pre_scale + o + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(P.pre_shift + o + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                psc[e + k] = a[k];
+                psh[e + k] = b[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(wo0 + (j - 1) * D) < (unsigned)P.W;
+    }
+    auto pre_row = [&](int ih, Chunk<T>(&row)[NCOL]) {
+        const bool rok = (unsigned)ih < (unsigned)P.H;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) dw_pre_apply<T>(row[j], psc, psh, pslope, rok && cok[j]);
+    };
     Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], nx[NCOL];
     load_row(ho0 - D, r0);
     load_row(ho0, r1);
     load_row(ho0 + D, r2);
+    if (PRE) {
+        pre_row(ho0 - D, r0);
+        pre_row(ho0, r1);
+        pre_row(ho0 + D, r2);
+    }
     T* y = reinterpret_cast<T*>(P.y) + (((long long)n * P.Ho + ho0) * P.Wo + wo0) * P.ldy + c;
     for (int ho = ho0; ho < ho1; ho += D) {
         if (ho + D < ho1) load_row(ho + 2 * D, nx);  // prefetch: consumed in the next iteration
@@ -210,11 +260,179 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(DwParams P) {
             }
         }
         y += (long long)D * P.Wo * P.ldy;
+        if (PRE && ho + D < ho1) pre_row(ho + 2 * D, nx);
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) {
             r0[j] = r1[j];
             r1[j] = r2[j];
             r2[j] = nx[j];
+        }
+    }
+}
+
+// dw_s1_kernel with the input rows prefetched through LDS instead of registers.  In dw_s1_kernel a wave has ONE input
+// row (6 KiB) in flight while it computes -- all the registers allow -- and a block's life is a chain of exposed
+// memory latencies: rocprofv3 put it at 3.1 TB/s where a copy of the same tensor runs at 4.5.  Here every wave owns a
+// ring of PF row slots in LDS that its own lanes fill by LDS-DMA (buffer_load ... lds: no VGPRs, lane i's 16 bytes land at
+// slot + 16 i, so a lane reads back exactly what it fetched and no barrier is needed) PF rows ahead of the row being
+// computed; the wait is a COUNTED s_waitcnt vmcnt.  gfx9 has one counter for loads and stores and retires them in issue
+// order, so the output stores are buffer stores that are ALWAYS issued (columns past the image edge fall outside the
+// row descriptor's range and are dropped): the number of younger operations at every wait is then known statically.
+// (non-template helper: see dma16 in igemm_conv.hip)
+__device__ __forceinline__ void dw_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst, 16, voffset, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void dw_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+constexpr int DW_PF = 3;                       // rows in flight per wave
+constexpr int DW_RING_LDS = 4 * DW_PF * 6 * 1024;  // 4 waves x PF slots x 6 columns x 1 KiB
+
+template <typename T, int FLIP, int PRE>
+__global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int TW = 4, NCOL = TW + 2, PF = DW_PF;
+    typedef typename Elem<T>::vec_t vec_t;
+    extern __shared__ __align__(16) char dw_smem[];
+    const unsigned cv = P.C / VEC;
+    int band, xblk;
+    dw_block_to_row(P.bx, band, xblk);
+    const unsigned idx = xblk * 256u + threadIdx.x;
+    if (idx >= (unsigned)P.items) return;
+    const unsigned wq = idx / cv;
+    const int c = (int)(idx - wq * cv) * VEC;
+    const int D = P.dil;
+    const int pc = (int)wq / P.wgroups, gi = (int)wq - pc * P.wgroups;  // column phase, group inside it
+    const int wo0 = pc + gi * TW * D;
+    const int n = band / P.bands, b = band - n * P.bands;
+    const int pr = b / P.bands_per_phase, bi = b - pr * P.bands_per_phase;  // row phase, band inside it
+    const int ho0 = pr + bi * P.rb * D;
+    const int ho1 = min(ho0 + P.rb * D, P.Ho);
+    const unsigned row_bytes = (unsigned)P.W * P.ldx * sizeof(T);
+    const unsigned orow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
+    const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * row_bytes;
+    char* yn = reinterpret_cast<char*>(P.y) + (long long)n * P.Ho * orow_bytes;
+    int voff[NCOL], goff[TW];  // negative (left of the image) -> huge unsigned -> out of range -> 0 / dropped
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 + (j - 1) * D) * P.ldx + c) * (int)sizeof(T);
+#pragma unroll
+    for (int t = 0; t < TW; ++t) goff[t] = ((wo0 + t * D) * P.ldy + c) * (int)sizeof(T);
+    Chunk<T> wv[9];
+    {
+        const T* w = reinterpret_cast<const T*>(P.w) + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t].load(w + (FLIP ? 8 - t : t) * P.C);
+    }
+    float psc[VEC], psh[VEC];
+    bool cok[NCOL];
+    const float pslope = act_max_slope(P.pre_act);
+    if (PRE) {
+        const long long o = (long long)(n / P.pre_ipg) * P.C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(P.pre_scale + o + e);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(P.pre_shift + o + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                psc[e + k] = a[k];
+                psh[e + k] = bq[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(wo0 + (j - 1) * D) < (unsigned)P.W;
+    }
+    const int lane = threadIdx.x & 63;
+    char* wb = dw_smem + (threadIdx.x >> 6) * (PF * NCOL * 1024);
+    const int nout = (ho1 - ho0 + D - 1) / D;  // output rows of this band (on its row phase)
+    const int Q = nout + 2;                    // input rows q = 0 .. Q-1 at image row ho0 + (q-1) D
+    auto issue_row = [&](int q, int slot) {
+        const int ih = ho0 + (q - 1) * D;
+        const bool ok = (unsigned)ih < (unsigned)P.H;  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(xn + (long long)(ok ? ih : 0) * row_bytes), 0, ok ? row_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) dw_dma16(rs, wb + (slot * NCOL + j) * 1024, voff[j]);
+    };
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+        if (q < Q) issue_row(q, q);
+    Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+        r1[j].zero();
+        r2[j].zero();
+    }
+    int slot = 0;
+    for (int q = 0; q < Q; ++q) {
+        const int rem = Q - 1 - q;  // input rows after this one
+        // younger operations than row q's six loads: steady state = this wave's 4 stores of iteration q-PF, then
+        // (6 loads + 4 stores) of each of the PF-1 iterations since; otherwise count only the rows issued after q
+        // (waiting for more than necessary is always safe)
+#if defined(DW_DBG_NOSTORE)
+        if (q >= PF + 2 && rem >= PF - 1) dw_wait_vmcnt<(PF - 1) * NCOL>();
+#else
+        if (q >= PF + 2 && rem >= PF - 1) dw_wait_vmcnt<TW + (PF - 1) * (NCOL + TW)>();
+#endif
+        else if (rem >= 2) dw_wait_vmcnt<2 * NCOL>();
+        else if (rem == 1) dw_wait_vmcnt<NCOL>();
+        else dw_wait_vmcnt<0>();
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            r0[j] = r1[j];
+            r1[j] = r2[j];
+            r2[j].v = *reinterpret_cast<const vec_t*>(wb + (slot * NCOL + j) * 1024 + lane * 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is read before the DMA below refills it
+        if (q + PF < Q) issue_row(q + PF, slot);
+        slot = slot + 1 == PF ? 0 : slot + 1;
+        if (PRE) {
+            const bool rok = (unsigned)(ho0 + (q - 1) * D) < (unsigned)P.H;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) dw_pre_apply<T>(r2[j], psc, psh, pslope, rok && cok[j]);
+        }
+        if (q < 2) continue;
+        float acc[TW][VEC];
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+#if defined(DW_DBG_NOCOMPUTE)  // timing experiment: the memory traffic without the arithmetic
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[t][e] = r1[t + 1].get(e) + r0[t].get(e) + r2[t + 2].get(e);
+#else
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    acc[t][e] = fmaf(r0[t + s].get(e), wv[0 + s].get(e), acc[t][e]);
+                    acc[t][e] = fmaf(r1[t + s].get(e), wv[3 + s].get(e), acc[t][e]);
+                    acc[t][e] = fmaf(r2[t + s].get(e), wv[6 + s].get(e), acc[t][e]);
+                }
+#endif
+#if defined(DW_DBG_NOSTORE)  // timing experiment: no stores issued (P.N is never negative)
+        if (P.N >= 0) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sum += acc[t][e];
+            if (sum != 12345.678f) continue;
+        }
+#endif
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            yn + (long long)(ho0 + (q - 2) * D) * orow_bytes, 0, orow_bytes, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.set(e, acc[t][e]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.v), ro, goff[t], 0, 0);
         }
     }
 }
@@ -353,6 +571,10 @@ struct DwWParams {
     int tx, log_tx;
     int gx, bands;  // dw_bwd_weight_s1_kernel: channel blocks, row bands per image
     int wgroups, bands_per_phase;  // ... column groups per column phase, bands per row phase (dilation)
+    const float* pre_scale;  // PRE = 1 (dw_bwd_weight_s1_kernel): x is a raw convolution output, see DwParams
+    const float* pre_shift;
+    int pre_act;
+    int pre_ipg;
 };
 
 template <typename T, int FAST /* stride 1, dilation 1: sliding 3-column window */>
@@ -461,7 +683,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwWParams P) {
 // 3-row input window in registers (x: 1.5 loads per output instead of 3; branch-free buffer loads,
 // out-of-image = 0), then moves to its next column group.  Block = TX channel vectors x TY column
 // lanes over one band of rows; partials are folded through LDS one tap at a time.
-template <typename T>
+template <typename T, int PRE>
 __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int TW = 4, NCOL = TW + 2;
@@ -489,6 +711,21 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
     const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * xrow_bytes;
     const char* gn = reinterpret_cast<const char*>(P.dy) + (long long)n * P.Ho * grow_bytes;
     const int nwq = D * P.wgroups;
+    float psc[VEC], psh[VEC];
+    const float pslope = act_max_slope(P.pre_act);
+    if (PRE && c_ok) {
+        const long long o = (long long)(n / P.pre_ipg) * P.C + c;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(P.pre_scale + o + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(P.pre_shift + o + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                psc[e + k] = a[k];
+                psh[e + k] = b[k];
+            }
+        }
+    }
     if (c_ok) {
         for (int wq = ly; wq < nwq; wq += ty) {
             const int pc = wq / P.wgroups, gi = wq - pc * P.wgroups;
@@ -506,10 +743,21 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
                 for (int j = 0; j < NCOL; ++j)
                     dst[j].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0));
             };
+            auto pre_row = [&](int ih, Chunk<T>(&row)[NCOL]) {
+                const bool rok = (unsigned)ih < (unsigned)P.H;
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j)
+                    dw_pre_apply<T>(row[j], psc, psh, pslope, rok && (unsigned)(wo0 + (j - 1) * D) < (unsigned)P.W);
+            };
             Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL], nx[NCOL], gv[TW];
             load_row(ho0 - D, r0);
             load_row(ho0, r1);
             load_row(ho0 + D, r2);
+            if (PRE) {
+                pre_row(ho0 - D, r0);
+                pre_row(ho0, r1);
+                pre_row(ho0 + D, r2);
+            }
             for (int ho = ho0; ho < ho1; ho += D) {
                 const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<char*>(gn + (long long)ho * grow_bytes), 0, grow_bytes, 0x00020000);
@@ -528,6 +776,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_s1_kernel(DwWParams P) {
                             acc[3 + s][e] = fmaf(g, r1[t + s].get(e), acc[3 + s][e]);
                             acc[6 + s][e] = fmaf(g, r2[t + s].get(e), acc[6 + s][e]);
                         }
+                if (PRE && ho + D < ho1) pre_row(ho + 2 * D, nx);
 #pragma unroll
                 for (int j = 0; j < NCOL; ++j) {
                     r0[j] = r1[j];
@@ -654,34 +903,119 @@ int check_dw(const bg_dwconv_desc* d, const char* who) {
     return BG_OK;
 }
 
+template <typename T, int FLIP, int PRE>
+void launch_dw_ring_t(const DwParams& P, unsigned blocks, hipStream_t st) {
+    static const bool once = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_ring_kernel<T, FLIP, PRE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, DW_RING_LDS) == hipSuccess;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((dw_ring_kernel<T, FLIP, PRE>), dim3(blocks), dim3(256), DW_RING_LDS, st, P);
+}
+
 // stride 1 / dilation 1 launcher shared by forward (flip 0) and data gradient (flip 1)
 int launch_dw_s1(int dtype, DwParams P, int flip, hipStream_t st, const char* who) {
-    static const int k_rb = getenv("BGAMD_DW_RB") ? atoi(getenv("BGAMD_DW_RB")) : 4;  // tuning knob
+    static const int k_rb = getenv("BGAMD_DW_RB") ? atoi(getenv("BGAMD_DW_RB")) : 0;  // tuning knob (0: chosen below)
+    static const bool ring = !(getenv("BGAMD_DW_RING") && atoi(getenv("BGAMD_DW_RING")) == 0);  // A/B switch
     const int cv = P.C / dtype_vec(dtype);
-    BG_CHECK_ARG((long long)P.W * P.ldx * 4 < 0x7fffffffLL, "%s: image row too large", who);
+    BG_CHECK_ARG((long long)P.W * P.ldx * 4 < 0x7fffffffLL && (long long)P.Wo * P.ldy * 4 < 0x7fffffffLL,
+                 "%s: image row too large", who);
     const int D = P.dil;
     const int vrows = (P.Ho + D - 1) / D, vcols = (P.Wo + D - 1) / D;  // rows / columns of one sub-lattice
-    P.rb = k_rb < vrows ? k_rb : vrows;
-    P.bands_per_phase = (vrows + P.rb - 1) / P.rb;
-    P.bands = D * P.bands_per_phase;
     P.wgroups = (vcols + 3) / 4;
     P.items = D * P.wgroups * cv;
     P.bx = (P.items + 255) / 256;
+    int rb = k_rb > 0 ? k_rb : 4;
+    if (ring && k_rb <= 0) {
+        // rows per band: long bands keep the prefetch ring in its steady state, but the launch should still fill the
+        // chip's 512 block slots (2 x 72 KiB of LDS per CU) in whole rounds -- take the band length in 4..16 with the
+        // best slot utilisation, the longer one on ties
+        double best = -1.0;
+        for (int r = 4; r <= 16; ++r) {
+            const long long nb = (long long)P.N * D * ((vrows + r - 1) / r) * P.bx;
+            const double eff = (double)nb / (double)((nb + 511) / 512 * 512);
+            if (eff >= best - 1e-9) { best = eff; rb = r; }
+        }
+    }
+    P.rb = rb < vrows ? rb : vrows;
+    P.bands_per_phase = (vrows + P.rb - 1) / P.rb;
+    P.bands = D * P.bands_per_phase;
     const long long blocks = (long long)P.N * P.bands * P.bx;
     BG_CHECK_ARG(blocks <= 0x7fffffffLL, "%s: grid too large", who);
-    if (flip) BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, P));
-    else BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+    const unsigned nb = (unsigned)blocks;
+    if (ring) {
+        if (flip) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 1, 0>(P, nb, st)));
+        else if (P.pre_scale) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 1>(P, nb, st)));
+        else BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 0>(P, nb, st)));
+    } else {
+        if (flip) BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 1, 0>), dim3(nb), dim3(256), 0, st, P));
+        else if (P.pre_scale) BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 0, 1>), dim3(nb), dim3(256), 0, st, P));
+        else BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 0, 0>), dim3(nb), dim3(256), 0, st, P));
+    }
     BG_CHECK_LAUNCH(who);
     return BG_OK;
 }
 
 }  // namespace
 
+namespace {
+struct DwPre {
+    const float* scale;
+    const float* shift;
+    int groups, act;
+};
+int check_pre(const bg_dwconv_desc* d, const DwPre& pre, const char* who) {
+    BG_CHECK_ARG(pre.scale && pre.shift && aligned16(pre.scale) && aligned16(pre.shift), "%s: null/unaligned scale/shift", who);
+    BG_CHECK_ARG(pre.groups >= 1 && d->N % pre.groups == 0, "%s: batch of %d does not split into %d groups", who, d->N, pre.groups);
+    BG_CHECK_ARG(pre.act >= 0 && pre.act <= 2, "%s: bad activation code", who);
+    BG_CHECK_ARG(d->stride == 1 && (d->dil == 1 || d->dil == 2), "%s: stride 1 with dilation 1 or 2 only", who);
+    BG_CHECK_ARG(d->C % 4 == 0, "%s: C must be a multiple of 4", who);
+    return BG_OK;
+}
+int dw_fwd_impl(const bg_dwconv_desc* d, const void* x, const DwPre* pre, const void* w, void* y, void* stream);
+int dw_bwd_weight_impl(const bg_dwconv_desc* d, const void* x, const DwPre* pre, const void* dy, float* dw, void* stream);
+}  // namespace
+
 extern "C" int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const void* w, void* y, void* stream) {
+    return dw_fwd_impl(d, x, nullptr, w, y, stream);
+}
+extern "C" int bg_dwconv3x3_fwd_pre(const bg_dwconv_desc* d, const void* x, const float* scale, const float* shift,
+                                    int32_t groups, int32_t act, const void* w, void* y, void* stream) {
+    int rc = check_dw(d, "bg_dwconv3x3_fwd_pre");
+    if (rc) return rc;
+    const DwPre pre{scale, shift, groups, act};
+    rc = check_pre(d, pre, "bg_dwconv3x3_fwd_pre");
+    if (rc) return rc;
+    return dw_fwd_impl(d, x, &pre, w, y, stream);
+}
+extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw,
+                                       void* stream) {
+    return dw_bwd_weight_impl(d, x, nullptr, dy, dw, stream);
+}
+extern "C" int bg_dwconv3x3_bwd_weight_pre(const bg_dwconv_desc* d, const void* x, const float* scale,
+                                           const float* shift, int32_t groups, int32_t act, const void* dy, float* dw,
+                                           void* stream) {
+    int rc = check_dw(d, "bg_dwconv3x3_bwd_weight_pre");
+    if (rc) return rc;
+    const DwPre pre{scale, shift, groups, act};
+    rc = check_pre(d, pre, "bg_dwconv3x3_bwd_weight_pre");
+    if (rc) return rc;
+    return dw_bwd_weight_impl(d, x, &pre, dy, dw, stream);
+}
+
+namespace {
+int dw_fwd_impl(const bg_dwconv_desc* d, const void* x, const DwPre* pre, const void* w, void* y, void* stream) {
     int rc = check_dw(d, "bg_dwconv3x3_fwd");
     if (rc) return rc;
     BG_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "bg_dwconv3x3_fwd: null/unaligned pointer");
     DwParams P{x, w, y, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0, 0};
+    if (pre) {
+        P.pre_scale = pre->scale;
+        P.pre_shift = pre->shift;
+        P.pre_act = pre->act;
+        P.pre_ipg = d->N / pre->groups;
+        return launch_dw_s1(d->dtype, P, 0, (hipStream_t)stream, "dw_s1_kernel(pre)");
+    }
     const long long rows = (long long)d->N * d->Ho;
     hipStream_t st = (hipStream_t)stream;
     const int cv = d->C / dtype_vec(d->dtype);
@@ -707,6 +1041,7 @@ extern "C" int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const vo
     BG_CHECK_LAUNCH("dw_fwd_kernel");
     return BG_OK;
 }
+}  // namespace
 
 extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, const void* w, void* dx, void* stream) {
     int rc = check_dw(d, "bg_dwconv3x3_bwd_data");
@@ -755,12 +1090,18 @@ extern "C" int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, co
     return BG_OK;
 }
 
-extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw,
-                                       void* stream) {
+namespace {
+int dw_bwd_weight_impl(const bg_dwconv_desc* d, const void* x, const DwPre* pre, const void* dy, float* dw, void* stream) {
     int rc = check_dw(d, "bg_dwconv3x3_bwd_weight");
     if (rc) return rc;
     BG_CHECK_ARG(x && dy && dw && aligned16(x) && aligned16(dy), "bg_dwconv3x3_bwd_weight: null/unaligned pointer");
     DwWParams P{x, dy, dw, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0, 0, 0, 0};
+    if (pre) {
+        P.pre_scale = pre->scale;
+        P.pre_shift = pre->shift;
+        P.pre_act = pre->act;
+        P.pre_ipg = d->N / pre->groups;
+    }
     const int cv = d->C / dtype_vec(d->dtype);
     int best = 16, best_pad = 1 << 30;
     for (int tx = 16; tx <= 64; tx *= 2) {
@@ -786,11 +1127,16 @@ extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, c
         P.gx = gx;
         const long long blocks = (long long)gx * d->N * P.bands;
         BG_CHECK_ARG(blocks <= 0x7fffffffLL, "bg_dwconv3x3_bwd_weight: grid too large");
-        BG_DISPATCH_DTYPE(d->dtype, T,
-                          hipLaunchKernelGGL((dw_bwd_weight_s1_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+        if (P.pre_scale)
+            BG_DISPATCH_DTYPE(d->dtype, T,
+                              hipLaunchKernelGGL((dw_bwd_weight_s1_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, P));
+        else
+            BG_DISPATCH_DTYPE(d->dtype, T,
+                              hipLaunchKernelGGL((dw_bwd_weight_s1_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, P));
         BG_CHECK_LAUNCH("dw_bwd_weight_s1_kernel");
         return BG_OK;
     }
+    BG_CHECK_ARG(!P.pre_scale, "bg_dwconv3x3_bwd_weight_pre: stride 1 with dilation 1 or 2 only");
     if (d->stride == 2 && d->dil == 1 && !old11 && !old_sd) {
         BG_CHECK_ARG((long long)d->W * d->ldx * 4 < 0x7fffffffLL && (long long)d->Wo * d->ldy * 4 < 0x7fffffffLL,
                      "bg_dwconv3x3_bwd_weight: image row too large");
@@ -820,3 +1166,4 @@ extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, c
     BG_CHECK_LAUNCH("dw_bwd_weight_kernel");
     return BG_OK;
 }
+}  // namespace

@@ -330,6 +330,39 @@ __global__ void norm_finalize_kernel(const double* sum, const double* sumsq, lon
     }
 }
 
+// The fused finalize of norm_act_fwd_kernel as a launch of its own, for consumers that apply the affine themselves
+// (bg_dwconv3x3_fwd_pre): the SAME arithmetic (fp64 mean / variance, fp32 rsqrt, norm_affine), so that the backward
+// kernels' recomputed activation branch agrees with what the consumer computed.  One thread per channel; statistic
+// groups are walked in order for the running-statistics update (one momentum step per group).
+__global__ void norm_finalize_affine_kernel(const double* sum, const double* sumsq, long long rpg, int groups, int C,
+                                            const float* gamma, const float* beta, float eps, float momentum,
+                                            float* rmean, float* rvar, float* mean, float* rstd, float* scale,
+                                            float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = (double)rpg;
+    const double inv_n = 1.0 / n;
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const long long i = (long long)g * C + c;
+        const double m = sum[i] * inv_n;
+        double var = sumsq[i] * inv_n - m * m;
+        if (var < 0.0 || rpg == 1) var = 0.0;
+        const float r = rsqrtf((float)var + eps);
+        mean[i] = (float)m;
+        rstd[i] = r;
+        norm_affine(gm, bt, (float)m, r, scale[i], shift[i]);
+        const double unb = rpg > 1 ? var * n / (n - 1.0) : var;
+        rm = (1.f - momentum) * rm + momentum * (float)m;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
+    }
+    if (rmean) {
+        rmean[c] = rm;
+        rvar[c] = rv;
+    }
+}
+
 __global__ void norm_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rmean,
                                         const float* rvar, float eps, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -804,6 +837,21 @@ extern "C" int bg_norm_finalize(const double* sum, const double* sumsq, int64_t 
                        (long long)rows_per_group, groups, C, gamma, beta, eps, momentum, running_mean, running_var, mean,
                        rstd, scale, shift);
     BG_CHECK_LAUNCH("norm_finalize_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_norm_finalize_affine(const double* sum, const double* sumsq, int64_t rows_per_group, int32_t groups,
+                                       int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* mean, float* rstd,
+                                       float* scale, float* shift, void* stream) {
+    BG_CHECK_ARG(sum && sumsq && mean && rstd && scale && shift && rows_per_group > 0 && groups > 0 && C > 0,
+                 "bg_norm_finalize_affine: bad args");
+    BG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
+                 "bg_norm_finalize_affine: running stats must come in pairs");
+    hipLaunchKernelGGL(norm_finalize_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sum, sumsq,
+                       (long long)rows_per_group, groups, C, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                       rstd, scale, shift);
+    BG_CHECK_LAUNCH("norm_finalize_affine_kernel");
     return BG_OK;
 }
 

@@ -590,6 +590,79 @@ class NormActFn(torch.autograd.Function):
         return (dx, dres) + (None,) * 15
 
 
+class NormActDwConvFn(torch.autograd.Function):
+    """dw3x3( act( BatchNorm2d_train(x) ) ): the [BatchNorm2d -> LeakyReLU -> SeparableConv2d_same.conv1] chain of the
+    Xception units (deeplab.py:75-87, 90-143) with the activated tensor never written to memory.  The statistics are
+    finalised into per-(group, channel) scale/shift (bg_norm_finalize_affine, which also applies the running-statistics
+    update), and the depthwise kernel applies them to every input chunk it loads (bg_dwconv3x3_fwd_pre).  Backward:
+    depthwise data gradient, depthwise weight gradient on the recomputed activation (bg_dwconv3x3_bwd_weight_pre), then
+    the BatchNorm backward of NormActFn with the activation branch recomputed from x.  Values are bit-identical to
+    NormActFn followed by DwConv3x3Fn."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, dw_weight, arena: Arena, gslot, bslot, wslot: ParamSlot, rmean, rvar, act, eps,
+                momentum, pre_stats, bn_groups, dil):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        dev, dt = x.device, L.dt(x.dtype)
+        rows = n * h * w
+        groups = bn_groups
+        assert n % groups == 0, f"batch of {n} does not split into {groups} statistic groups"
+        assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
+        if pre_stats is not None and pre_stats.shape[1] == groups:
+            s = pre_stats
+        else:
+            s = _f64(2, groups, c, device=dev)
+            L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
+        mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
+        upd = rmean is not None
+        L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
+               arena.master_ptr(gslot), arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None,
+               rvar.data_ptr() if upd else None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+        y = new_act(n, h, w, c, x.dtype, dev)
+        desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
+        L.call("bg_dwconv3x3_fwd_pre", desc, x.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, int(act),
+               arena.weight_ptr(wslot), y.data_ptr())
+        ctx.save_for_backward(x, mean, rstd, scale, shift)
+        ctx.meta = (arena, gslot, bslot, wslot, int(act), groups, dil)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd, scale, shift = ctx.saved_tensors
+        arena, gslot, bslot, wslot, act, groups, dil = ctx.meta
+        g = nhwc(g)
+        n, h, w, c = x.shape
+        dev, dt = x.device, L.dt(x.dtype)
+        rows = n * h * w
+        if ctx.needs_input_grad[3]:
+            arena.ensure_grad(wslot)
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+            wgrad_call(dev, (x, g, scale, shift), "bg_dwconv3x3_bwd_weight_pre", desc, x.data_ptr(), scale.data_ptr(),
+                       shift.data_ptr(), groups, act, g.data_ptr(), arena.grad_ptr(wslot))
+        need_dx = ctx.needs_input_grad[0]
+        want_affine_grads = gslot.param.requires_grad
+        if not (need_dx or want_affine_grads):
+            return (None,) * 16
+        da = new_act(n, h, w, c, x.dtype, dev)   # gradient of the activated tensor
+        desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(da), ld_of(g))
+        L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), da.data_ptr())
+        gptr, bptr = arena.master_ptr(gslot), arena.master_ptr(bslot)
+        s = _f64(2, groups, c, device=dev)
+        L.call("bg_norm_act_bwd_reduce", dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x), mean.data_ptr(),
+               rstd.data_ptr(), gptr, bptr, rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
+        dg = db = None
+        if want_affine_grads:
+            arena.ensure_grad(gslot)
+            arena.ensure_grad(bslot)
+            dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
+        dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
+        L.call("bg_norm_act_bwd_apply_stats", dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x),
+               s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx),
+               0 if dx is None else ld_of(dx), None, 0, rows, c, groups, act)
+        return (dx,) + (None,) * 15
+
+
 def leaky_relu(x):
     """Stand-alone LeakyReLU(0.2) (a Block called on a not-yet-activated input)."""
     return NormActFn.apply(x, None, None, None, None, None, None, None, None, "identity", False, True, 0.0, 0.0)

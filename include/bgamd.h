@@ -133,6 +133,17 @@ typedef struct bg_dwconv_desc {
 int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const void* w, void* y, void* stream);
 int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, const void* w, void* dx, void* stream);
 int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+/* The same two kernels with the producer's normalisation + activation applied to every loaded input chunk:
+ * the depthwise convolution (and its weight gradient) of act(x*scale[g,c] + shift[g,c]) where x is the RAW output
+ * of the previous pointwise convolution -- the activated tensor of the reference's
+ * [BatchNorm2d -> LeakyReLU -> SeparableConv2d_same] chain (deeplab.py:90-143) is never written to memory.
+ * scale/shift: fp32 [groups, C] from bg_norm_finalize_affine (image n belongs to group n / (N/groups)); the "same"
+ * zero padding applies to the activated tensor; values are rounded to the storage type exactly as
+ * bg_norm_act_fwd would have stored them, so both pipelines give identical bits.  Stride 1, dilation 1 or 2. */
+int bg_dwconv3x3_fwd_pre(const bg_dwconv_desc* d, const void* x, const float* scale, const float* shift,
+                         int32_t groups, int32_t act, const void* w, void* y, void* stream);
+int bg_dwconv3x3_bwd_weight_pre(const bg_dwconv_desc* d, const void* x, const float* scale, const float* shift,
+                                int32_t groups, int32_t act, const void* dy, float* dw, void* stream);
 
 /* ---------------------------------------------------------------------------
  * 3-D DeepLab GAN path (architecture/gpsro/deeplab3d.py).  A volume [N,D,H,W,C] is the
@@ -235,6 +246,12 @@ int bg_norm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int32_t
 int bg_norm_finalize(const double* sum, const double* sumsq, int64_t rows_per_group, int32_t groups, int32_t C,
                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* bg_norm_finalize with the arithmetic of bg_norm_act_fwd_stats' fused finalize (fp32 rsqrt, the affine formed the
+ * way the backward kernels re-form it) and one running-statistics update per statistic group, in group order:
+ * for consumers that apply the affine themselves (bg_dwconv3x3_fwd_pre). */
+int bg_norm_finalize_affine(const double* sum, const double* sumsq, int64_t rows_per_group, int32_t groups, int32_t C,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
 /* eval mode: scale/shift from running statistics. */
 int bg_norm_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift, void* stream);

@@ -98,6 +98,16 @@ def main():
             i = nxt()
             L.call("bg_dwconv3x3_bwd_weight", desc, xs[i].data_ptr(), gs[i].data_ptr(), dwg.data_ptr())
 
+        def dw_fwd_pre():
+            i = nxt()
+            L.call("bg_dwconv3x3_fwd_pre", desc, xs[i].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, 1, wdw.data_ptr(),
+                   ys[i].data_ptr())
+
+        def dw_bwd_weight_pre():
+            i = nxt()
+            L.call("bg_dwconv3x3_bwd_weight_pre", desc, xs[i].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, 1,
+                   gs[i].data_ptr(), dwg.data_ptr())
+
         def copy():
             i = nxt()
             ys[i].copy_(xs[i])
@@ -105,7 +115,8 @@ def main():
         cases = [("copy(torch)", copy, 2), ("norm_stats", stats, 1), ("norm_act_fwd_stats", fwd_stats, 2), ("norm_act_fwd(plain)", fwd_plain, 2),
                  ("norm_finalize", finalize, 0),
                  ("bwd_reduce", bwd_reduce, 2), ("bwd_apply_stats", bwd_apply, 3), ("dw_fwd", dw_fwd, 2),
-                 ("dw_bwd_data", dw_bwd_data, 2), ("dw_bwd_weight", dw_bwd_weight, 2)]
+                 ("dw_bwd_data", dw_bwd_data, 2), ("dw_bwd_weight", dw_bwd_weight, 2), ("dw_fwd_pre", dw_fwd_pre, 2),
+                 ("dw_bwd_weight_pre", dw_bwd_weight_pre, 2)]
         for name, fn, k in cases:
             if only and not any(o in name for o in only):
                 continue

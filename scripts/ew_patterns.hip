@@ -103,6 +103,65 @@ __global__ __launch_bounds__(256) void v4(const u32x4* x, u32x4* y, long long n,
     }
 }
 
+// V6: the depthwise kernel's READ pattern alone: thread = (4-pixel column group, channel chunk) of an image row band,
+// reads 6 consecutive pixels' chunks of R+2 rows (ld 736 elements), no stores unless the sum is a magic value.
+template <int R, int COLS>
+__global__ __launch_bounds__(256) void v6(const u32x4* x, u32x4* y, int H, int W, float magic) {
+    const int cv = 91, ldc = 92;  // chunks per pixel / per pixel stride
+    const int wgroups = W / 4, items = wgroups * cv, bx = (items + 255) / 256;
+    const int band = blockIdx.x / bx, xblk = blockIdx.x - band * bx;
+    const int idx = xblk * 256 + threadIdx.x;
+    if (idx >= items) return;
+    const int wq = idx / cv, c = idx - wq * cv;
+    const int bands = H / R, n = band / bands, b = band - n * bands;
+    const long long row_chunks = (long long)W * ldc;
+    const u32x4* xn = x + (long long)n * H * row_chunks;
+    u32x4 acc = {0, 0, 0, 0};
+    for (int r = -1; r <= R; ++r) {
+        const int ih = b * R + r;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            const int col = wq * 4 + j - (COLS > 4 ? 1 : 0);
+            if (col < 0 || col >= W) continue;
+            acc ^= xn[ih * row_chunks + (long long)col * ldc + c];
+        }
+    }
+    if (__uint_as_float(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == magic) y[idx] = acc;
+}
+
+// V7: V6 with every load of the band issued before the first use (clamped addresses instead of branches)
+template <int R, int COLS>
+__global__ __launch_bounds__(256) void v7(const u32x4* x, u32x4* y, int H, int W, float magic) {
+    const int cv = 91, ldc = 92;
+    const int wgroups = W / 4, items = wgroups * cv, bx = (items + 255) / 256;
+    const int band = blockIdx.x / bx, xblk = blockIdx.x - band * bx;
+    const int idx = xblk * 256 + threadIdx.x;
+    if (idx >= items) return;
+    const int wq = idx / cv, c = idx - wq * cv;
+    const int bands = H / R, n = band / bands, b = band - n * bands;
+    const long long row_chunks = (long long)W * ldc;
+    const u32x4* xn = x + (long long)n * H * row_chunks;
+    u32x4 v[R + 2][COLS];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+        int ih = b * R + r - 1;
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            int col = wq * 4 + j - (COLS > 4 ? 1 : 0);
+            col = col < 0 ? 0 : (col >= W ? W - 1 : col);
+            v[r][j] = xn[ih * row_chunks + (long long)col * ldc + c];
+        }
+    }
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) acc ^= v[r][j];
+    if (__uint_as_float(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == magic) y[idx] = acc;
+}
+
 #define CK(e)                                                                   \
     do {                                                                        \
         hipError_t r_ = (e);                                                    \
@@ -177,6 +236,28 @@ int main() {
             run("lib norm_act_fwd flat C=256", [&](const u32x4* x, u32x4* y) {
                 if (bg_norm_act_fwd(BG_BF16, x, 256, f, f + 736, nullptr, 0, y, 256, rows * 736 / 256, 256, 1, 1, st)) exit(2);
             });
+            {   // depthwise 3x3 on the same tensor viewed as 8 x H x W x 728 (ld 736)
+                const int W = 48 * (s + 1), H = (int)(rows / 8 / W);
+#define V6(R, COLS) run("v6 dw read pattern R=" #R " cols=" #COLS, [&](const u32x4* x, u32x4* y) { \
+                    const int bx = ((W / 4) * 91 + 255) / 256; \
+                    hipLaunchKernelGGL((v6<R, COLS>), dim3(8 * (H / R) * bx), dim3(256), 0, st, x, y, H, W, 1.2345e-30f); })
+                V6(6, 6); V6(6, 4); V6(12, 6); V6(3, 6); V6(72, 4);
+#define V7(R, COLS) run("v7 all loads upfront R=" #R " cols=" #COLS, [&](const u32x4* x, u32x4* y) { \
+                    const int bx = ((W / 4) * 91 + 255) / 256; \
+                    hipLaunchKernelGGL((v7<R, COLS>), dim3(8 * (H / R) * bx), dim3(256), 0, st, x, y, H, W, 1.2345e-30f); })
+                V7(6, 6); V7(6, 4); V7(3, 6); V7(2, 6);
+                bg_dwconv_desc d{BG_BF16, 8, H, W, 728, H, W, 1, 1, 736, 736};
+                void* wdw;
+                CK(hipMalloc(&wdw, 9 * 736 * 2));
+                CK(hipMemset(wdw, 0x3c, 9 * 736 * 2));
+                run("lib dwconv3x3_fwd", [&](const u32x4* x, u32x4* y) {
+                    if (bg_dwconv3x3_fwd(&d, x, wdw, y, st)) exit(2);
+                });
+                run("lib dwconv3x3_fwd_pre", [&](const u32x4* x, u32x4* y) {
+                    if (bg_dwconv3x3_fwd_pre(&d, x, f, f + 736, 1, 1, wdw, y, st)) exit(2);
+                });
+                CK(hipFree(wdw));
+            }
             CK(hipFree(sums));
             CK(hipFree(f));
         }

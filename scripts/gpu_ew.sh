@@ -2,7 +2,9 @@
 # element-wise / reduce micro-bench at the step's activation shapes + the kernel parity tests
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 120 ./build_tmp/ew_patterns > gpurun_out/ew_patterns.log 2>&1; grep "lib\|hipMemcpy" gpurun_out/ew_patterns.log
-timeout -k 10 300 python scripts/bench_ew.py 2>&1 | grep -v amdgpu > gpurun_out/ew.log
-cat gpurun_out/ew.log | grep "72x48\|144x96" 
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "dwconv" 2>&1 | tail -5 || exit 1
+for cfg in "BGAMD_DW_RING=1" "BGAMD_DW_RING=0"; do
+echo "== $cfg"
+env $cfg timeout -k 10 300 python scripts/bench_ew.py copy dw_ 2>&1 | grep -v amdgpu > gpurun_out/ew_$cfg.log
+cat gpurun_out/ew_$cfg.log
+done

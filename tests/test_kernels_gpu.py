@@ -855,6 +855,71 @@ def test_norm_act_bwd_sign_recomputed_from_x(dtype, mode):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(4, 13, 18, 16, 1, 2, 1), (2, 9, 7, 728, 1, 1, 1), (4, 16, 12, 24, 2, 2, 1), (2, 6, 5, 40, 1, 1, 0),
+                                  (2, 11, 50, 264, 1, 1, 2)])
+def test_dwconv_with_norm_act_prologue(case, dtype):
+    """bg_dwconv3x3_fwd_pre / bg_dwconv3x3_bwd_weight_pre (the producer's BatchNorm affine + activation applied to every
+    loaded chunk, the activated tensor never stored) against bg_norm_finalize_affine + bg_norm_act_fwd followed by the
+    plain depthwise kernels: the forward output must be IDENTICAL bit for bit, the weight gradient equal up to the
+    arrival order of its fp32 atomics.  Statistic groups, dilation 2 and all three activation codes are covered; the
+    mean / rstd / running statistics of bg_norm_finalize_affine are checked against bg_norm_act_fwd_stats' fused finalize."""
+    n, h, w, c, d, groups, act = case
+    cp = up(c, dtype)
+    x = (rnd((n, c, h, w), 61, dtype, 2.0) + 0.4).to(dtype).float()
+    wt = rnd((c, 1, 3, 3), 62, dtype, 0.3)
+    go = rnd((n, c, h, w), 63, dtype)
+    ld = cp + 8
+    (xb, xv), (gb, gv) = to_nhwc(x, dtype, ld, 8), to_nhwc(go, dtype, ld, 8)
+    wk = torch.zeros(3, 3, cp, dtype=dtype, device=DEV)
+    wk[:, :, :c] = wt[:, 0].permute(1, 2, 0).to(dtype).to(DEV)
+    rows, dtc = n * h * w, L.dt(dtype)
+    gamma = (torch.rand(cp) - 0.3).to(DEV)      # negative gammas included
+    beta = (torch.randn(cp) * 0.2).to(DEV)
+    f32 = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    f64 = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.float64)  # noqa: E731
+    s, ss = f64(groups, cp), f64(groups, cp)
+    L.call("bg_norm_stats", dtc, xv.data_ptr(), rows, cp, ld, groups, s.data_ptr(), ss.data_ptr())
+    # reference pipeline: fused-finalize apply kernel, then the plain depthwise kernels
+    rm0, rv0 = torch.full((cp,), 0.1, device=DEV), torch.full((cp,), 0.9, device=DEV)
+    mean0, rstd0 = f32(groups, cp), f32(groups, cp)
+    a = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_norm_act_fwd_stats", dtc, xv.data_ptr(), ld, s.data_ptr(), ss.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+           1e-5, 0.1, rm0.data_ptr(), rv0.data_ptr(), mean0.data_ptr(), rstd0.data_ptr(), None, 0, a[..., 8:].data_ptr(), ld,
+           rows, cp, groups, act)
+    desc = L.DwDesc(dtc, n, h, w, cp, h, w, 1, d, ld, ld)
+    y0 = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_fwd", desc, a[..., 8:].data_ptr(), wk.data_ptr(), y0[..., 8:].data_ptr())
+    dw0 = f32(3, 3, cp)
+    L.call("bg_dwconv3x3_bwd_weight", desc, a[..., 8:].data_ptr(), gv.data_ptr(), dw0.data_ptr())
+    # fused pipeline
+    rm1, rv1 = torch.full((cp,), 0.1, device=DEV), torch.full((cp,), 0.9, device=DEV)
+    mean1, rstd1, scale, shift = f32(groups, cp), f32(groups, cp), f32(groups, cp), f32(groups, cp)
+    L.call("bg_norm_finalize_affine", s.data_ptr(), ss.data_ptr(), rows // groups, groups, cp, gamma.data_ptr(), beta.data_ptr(),
+           1e-5, 0.1, rm1.data_ptr(), rv1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    y1 = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_fwd_pre", desc, xv.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, act, wk.data_ptr(),
+           y1[..., 8:].data_ptr())
+    dw1 = f32(3, 3, cp)
+    L.call("bg_dwconv3x3_bwd_weight_pre", desc, xv.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, act, gv.data_ptr(),
+           dw1.data_ptr())
+    assert torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    assert_close(rm1.cpu(), rm0.cpu(), 1e-6, "running_mean")  # same formula; the compiler contracts the two copies differently
+    assert_close(rv1.cpu(), rv0.cpu(), 1e-6, "running_var")
+    assert torch.equal(y0, y1), (y0.float() - y1.float()).abs().max().item()
+    assert y0[..., 8:].float().abs().sum().item() > 0
+    assert_close(dw1.cpu(), dw0.cpu(), 1e-5, "dw wgrad (fused prologue)")
+    # and against torch in fp32 on the bf16-rounded activation the reference pipeline stored
+    ar = from_nhwc(a[..., 8:], c)
+    ref = F.conv2d(F.pad(ar, (d, d, d, d)), wt, None, 1, 0, d, groups=c)
+    assert_close(from_nhwc(y1[..., 8:], c), ref, tol(dtype), "dw fwd (fused prologue) vs torch")
+    # unsupported geometry is refused, not silently mis-computed
+    bad = L.DwDesc(dtc, n, h, w, cp, -(-h // 2), -(-w // 2), 2, 1, ld, ld)
+    with pytest.raises(RuntimeError):
+        L.call("bg_dwconv3x3_fwd_pre", bad, xv.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, act, wk.data_ptr(),
+               y1[..., 8:].data_ptr())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("p", [0, 1])
 def test_avgpool2x2(dtype, p):
     """bg_avgpool2x2 forward and adjoint vs F.avg_pool2d(2, 1, p) (count_include_pad default)."""

@@ -99,6 +99,46 @@ def test_block_vs_reference_golden(golden_dir, tag, dtype):
     assert ref_m
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("tag", ["blk_a", "blk_b", "blk_c", "blk_d"])
+def test_block_norm_inside_depthwise_matches_separate_passes(golden_dir, tag, dtype, monkeypatch):
+    """Block with the BatchNorm affine + LeakyReLU applied inside the next unit's depthwise kernel
+    (ops.NormActDwConvFn, the default) against the same Block with separate normalisation passes
+    (BGAMD_NO_FUSED_DW): the fused kernels round where the separate ones stored, so the forward output is
+    identical bit for bit; running statistics and gradients agree up to atomics' arrival order."""
+    z, _ = gz(golden_dir, "modules.npz")
+    kw = json.loads(str(z[tag + "::cfg"]))
+    sd = {k[len(tag) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "::sd::")}
+    out = {}
+    for fused in (False, True):
+        monkeypatch.setattr(dl, "_FUSED_DW", fused)
+        calls = []
+        orig = ops.NormActDwConvFn.apply
+        monkeypatch.setattr(ops.NormActDwConvFn, "apply", lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
+        blk = dl.Block(normalizer=nn.BatchNorm2d, **kw)
+        blk.load_state_dict(sd)
+        blk.set_compute_dtype(dtype).to(DEV).train()
+        x = torch.from_numpy(z[tag + "::x"]).to(DEV).requires_grad_(True)
+        xi = ops.ToInternal.apply(x, pad_to(x.shape[1], vec_of(dtype)), dtype)
+        y = ops.FromInternal.apply(blk(xi), kw["planes"])
+        y.backward(torch.from_numpy(z[tag + "::go"]).to(DEV))
+        torch.cuda.synchronize()
+        out[fused] = (y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in blk.named_parameters()},
+                      {k: v.cpu() for k, v in blk.state_dict().items() if "running" in k}, len(calls))
+        monkeypatch.setattr(ops.NormActDwConvFn, "apply", orig)
+    a, b = out[False], out[True]
+    assert a[4] == 0
+    n_sep = sum(isinstance(u, dl.SeparableConv2d_same) for u in dl.Block(normalizer=nn.BatchNorm2d, **kw).rep)
+    if n_sep >= 3:
+        assert b[4] >= 1, "the fused path did not engage"
+    assert torch.equal(a[0], b[0])
+    for k in a[3]:
+        assert rel_err(b[3][k], a[3][k]) <= 1e-6, k
+    assert rel_err(b[1], a[1]) <= 1e-5
+    for k in a[2]:
+        assert rel_err(b[2][k], a[2][k]) <= 2e-5, k
+
+
 def build_generator(c, seed, dtype, norm=nn.BatchNorm2d, upsampler="Interpolate"):
     spec = orc.generator_spec(c, c, 0, "batch", upsampler=upsampler)
     G = dxg.Generator(c, c, upsampler, "Uniform", 0, normalizer=norm, compute_dtype=dtype)
