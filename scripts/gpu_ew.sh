@@ -3,8 +3,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "dwconv" 2>&1 | tail -5 || exit 1
-for cfg in "BGAMD_DW_RING=1" "BGAMD_DW_RING=0"; do
-echo "== $cfg"
-env $cfg timeout -k 10 300 python scripts/bench_ew.py copy dw_ 2>&1 | grep -v amdgpu > gpurun_out/ew_$cfg.log
-cat gpurun_out/ew_$cfg.log
-done
+timeout -k 10 300 python scripts/bench_ew.py ${EW_CASES:-copy dw_} 2>&1 | grep -v amdgpu > gpurun_out/ew.log
+cat gpurun_out/ew.log
