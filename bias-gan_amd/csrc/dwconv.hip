@@ -927,14 +927,18 @@ int launch_dw_s1(int dtype, DwParams P, int flip, hipStream_t st, const char* wh
     P.bx = (P.items + 255) / 256;
     int rb = k_rb > 0 ? k_rb : 4;
     if (ring && k_rb <= 0) {
-        // rows per band: long bands keep the prefetch ring in its steady state, but the launch should still fill the
-        // chip's 512 block slots (2 x 72 KiB of LDS per CU) in whole rounds -- take the band length in 4..16 with the
-        // best slot utilisation, the longer one on ties
-        double best = -1.0;
-        for (int r = 4; r <= 16; ++r) {
-            const long long nb = (long long)P.N * D * ((vrows + r - 1) / r) * P.bx;
-            const double eff = (double)nb / (double)((nb + 511) / 512 * 512);
-            if (eff >= best - 1e-9) { best = eff; rb = r; }
+        // rows per band: ONE round of at most one workgroup per CU wherever the launch allows it -- measured over band
+        // lengths 3..144 on the step's shapes (scripts/gpu_rb.sh), the fastest launch was always the one with 190-256
+        // workgroups (8 x 72 x 48 x 728: 23.7 us at 240 workgroups against 26.5 at 480 and 25.9 at 720; 8 x 144 x 96 x 728:
+        // 67.9 at 216 against 78.2), i.e. long bands that keep the prefetch ring in its steady state and no second
+        // round; tensors too large for that (the entry flow: > 256 workgroups even with one band per image) are
+        // insensitive and keep short bands
+        const long long per_band = (long long)P.N * D * P.bx;
+        if (per_band <= 256) {
+            const int nbands = (int)(256 / per_band);
+            rb = (vrows + nbands - 1) / nbands;
+        } else {
+            rb = 6;
         }
     }
     P.rb = rb < vrows ? rb : vrows;
@@ -1115,7 +1119,13 @@ int dw_bwd_weight_impl(const bg_dwconv_desc* d, const void* x, const DwPre* pre,
     static const bool old11 = getenv("BGAMD_DW_OLD") != nullptr;  // A/B switch
     static const bool old_sd = getenv("BGAMD_DW_SD_OLD") != nullptr;
     if (d->stride == 1 && (d->dil == 1 || (d->dil == 2 && !old_sd)) && !old11) {
-        static const int k_rb = getenv("BGAMD_DWW_RB") ? atoi(getenv("BGAMD_DWW_RB")) : 4;  // tuning knob
+        static const int k_rb_env = getenv("BGAMD_DWW_RB") ? atoi(getenv("BGAMD_DWW_RB")) : 0;  // tuning knob
+        // rows per band (scripts/gpu_rbw.sh, band lengths 4..72): 4 on the 72-row maps of the middle flow, 8-9 on
+        // the taller maps of the entry flow (8 x 144 x 96 x 728: 80.6 -> 73.5 us, 8 x 288 x 192 x 256: 110 -> 98, 8 x 576 x 384 x 128:
+        // 189 -> 170) -- a thread walks its band once per column group, so band length trades launch width for fewer
+        // window refills
+        const int vrows_ = (d->Ho + d->dil - 1) / d->dil;
+        const int k_rb = k_rb_env > 0 ? k_rb_env : (vrows_ >= 256 ? 9 : (vrows_ >= 128 ? 8 : 4));
         BG_CHECK_ARG((long long)d->W * d->ldx * 4 < 0x7fffffffLL && (long long)d->Wo * d->ldy * 4 < 0x7fffffffLL,
                      "bg_dwconv3x3_bwd_weight: image row too large");
         const int D = d->dil;
