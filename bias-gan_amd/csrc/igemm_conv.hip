@@ -808,6 +808,138 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
     }
 }
 
+template <typename T, int MI, int NJ, int WM, int WN, bool STATS>
+__device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, f32x4 (&acc)[MI][NJ], int p_base, int rows_valid,
+                                                       int grp, int c_base, int wave_c, int wave_p, int lane, char* smem) {
+    constexpr int TM = WM * MI * 16, ES = (int)sizeof(T);
+    constexpr int CHB = MI * 16 * ES;      // bytes of one pixel's channels in this wave's sub-tile
+    constexpr int ROWB = CHB + 16;         // padded LDS row
+    constexpr int CPP = CHB / 16;          // 16-byte chunks per pixel
+    constexpr int NST = 16 * CPP / 64;     // store instructions per 16-pixel block
+    constexpr int REGION = 16 * ROWB;
+    static_assert((16 * CPP) % 64 == 0, "a 16-pixel block must be whole wave instructions");
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wave = wave_c * WN + wave_p;
+    T* out_tile = reinterpret_cast<T*>(P.out) + (long long)p_base * P.ldo;
+    const long long rem = (((long long)P.M - p_base - 1) * P.ldo + P.NO) * ES;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
+    constexpr bool stats = STATS;   // compile-time: with run-time flags the per-value code carried 216 selects and 435 moves
+    char* region = smem + wave * REGION;                               // this wave's transposition buffer
+    float* red = reinterpret_cast<float*>(smem + WM * WN * REGION);   // [wave_p][TM channels][2]
+    static_assert(WM * WN * REGION + WN * TM * 8 <= 96 * 1024, "epilogue scratch must fit the smallest staging ring that uses it");
+    __syncthreads();   // every wave is done reading the staging ring: reuse it
+
+    // read-back geometry: chunk ci of the block's 16 * CPP is (pixel ci / CPP, 16-byte chunk ci % CPP)
+    int rd_off[NST], st_coff[NST], st_pix[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int ci = t * 64 + lane;
+        const int pix = ci / CPP, ch = ci - pix * CPP;
+        rd_off[t] = pix * ROWB + ch * 16;
+        const int co = c_base + wave_c * MI * 16 + ch * (16 / ES);
+        st_coff[t] = co < P.NO ? co * ES : OOB;      // Cout is a multiple of the 16-byte vector
+        st_pix[t] = wave_p * NJ * 16 + pix;
+    }
+    float s1[MI][4], s2[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
+    const int wr_off = r16 * ROWB + q * 4 * ES;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const f32x4 v = acc[i][j];
+            if constexpr (sizeof(T) == 2) {
+                const bf16x4 ov = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(region + wr_off + i * 16 * ES) = ov;
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = (float)ov[e];
+                        s1[i][e] += r;
+                        s2[i][e] = fmaf(r, r, s2[i][e]);
+                    }
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(region + wr_off + i * 16 * ES) = v;
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[i][e] += v[e];
+                        s2[i][e] = fmaf(v[e], v[e], s2[i][e]);
+                    }
+                }
+            }
+        }
+        // the region is private to the wave and a wave's LDS instructions execute in order: no barrier
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(region + rd_off[t]);
+            const int row = st_pix[t] + j * 16;
+            const int roff = row < rows_valid ? row * P.ldo * ES : OOB;
+            const int off = (roff | st_coff[t]) < 0 ? OOB : roff + st_coff[t];
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, off, 0, 0);
+        }
+    }
+    if (stats) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[i][e] = row16_sum(s1[i][e]);
+                s2[i][e] = row16_sum(s2[i][e]);
+            }
+        if (r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cl = wave_c * MI * 16 + i * 16 + q * 4 + e;
+                    red[(wave_p * TM + cl) * 2 + 0] = s1[i][e];
+                    red[(wave_p * TM + cl) * 2 + 1] = s2[i][e];
+                }
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < TM && c_base + t < P.NO) {
+            const long long o = (long long)grp * P.NO + c_base + t;
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wp = 0; wp < WN; ++wp) {
+                a1 += red[(wp * TM + t) * 2];
+                a2 += red[(wp * TM + t) * 2 + 1];
+            }
+            atomicAdd(P.stat_sum + o, (double)a1);
+            atomicAdd(P.stat_sq + o, (double)a2);
+        }
+    }
+}
+
+// The fat bf16 kernels' entry: bias (the few layers that have one) is added once up front under a wave-uniform branch and
+// the statistics variant is a compile-time copy of the epilogue (2 352 -> ~1 500 / ~700 instructions per wave; 39.6 -> 37.7 us
+// on the 728 -> 728 launch with statistics).  The 64 x 64-per-wave kernels and the fp32 fat tiles keep the run-time-flag
+// version above: the two inlined copies cost them 12-30 registers, i.e. a wave of occupancy or spills.
+template <typename T, int MI, int NJ, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_fat_ct(const GemmConvParams& P, f32x4 (&acc)[MI][NJ], int p_base, int rows_valid,
+                                                     int grp, int c_base, int wave_c, int wave_p, int lane, char* smem) {
+    if (P.bias) {
+        const int q = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int co = c_base + wave_c * MI * 16 + i * 16 + q * 4;
+            const f32x4 bv = co < P.NO ? *reinterpret_cast<const f32x4*>(P.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] += bv;
+        }
+    }
+    if (P.stat_sum) conv_epilogue_fat_impl<T, MI, NJ, WM, WN, true>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
+    else conv_epilogue_fat_impl<T, MI, NJ, WM, WN, false>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
+}
+
 // PW1: a single tap (1x1 convolutions): the address set-up runs once and its registers are free in the K loop.
 // BKB: bytes of K per row and K-step.  128 = whole cache lines per row (a 1-KiB DMA piece is 8 rows x 128 B), two
 // stages of 80 KiB: a stage is issued right after the barrier that retires its predecessor and has the 84 MFMAs per wave
@@ -1059,7 +1191,8 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
     }
     BG_STAMP(3);
     BG_STAMP_CYC(7);
-    conv_epilogue_fat<T, MI, NJ, WM, WN>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
+    if constexpr (sizeof(T) == 2) conv_epilogue_fat_ct<T, MI, NJ, WM, WN>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
+    else conv_epilogue_fat<T, MI, NJ, WM, WN>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
 #ifdef BG_STAMPS
     BG_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
