@@ -131,6 +131,24 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// The same reduction for N values at once with the rotate folded into the add (v_add_f32_dpp: the compiler emits
+// v_mov_b32_dpp + v_add_f32 for row16_sum, 8 instructions per value instead of 4).  Each step runs over all N values
+// before the next step starts, so a value's dependent DPP read is N instructions behind its write (a DPP source written
+// by the preceding VALU instructions needs two wait states that nothing inserts inside inline assembly): N >= 4.
+template <int N>
+__device__ __forceinline__ void row16_sum_all(float (&v)[N]) {
+    static_assert(N >= 4, "dependent DPP reads must be at least three instructions apart");
+#define BG_ROR_ADD(n)                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < N; ++k)                                                                  \
+        asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(v[k]) : "v"(v[k]));
+    asm volatile("s_nop 4");   // whatever wrote v[] or EXEC just before: a DPP read needs up to five wait states after it
+    BG_ROR_ADD(8)
+    BG_ROR_ADD(4)
+    BG_ROR_ADD(2)
+    BG_ROR_ADD(1)
+#undef BG_ROR_ADD
+}
+
 // Epilogue shared by both staging variants.  A lane holds, per accumulator, 4
 // consecutive output channels of one pixel -> 8/16-byte NHWC stores.  With
 // P.stat_sum set it also reduces sum(y) and sum(y^2) of the values AS STORED
@@ -886,13 +904,24 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
         }
     }
     if (stats) {  // wave-uniform
+        {
+            float all[MI * 8];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s1[i][e] = row16_sum(s1[i][e]);
-                s2[i][e] = row16_sum(s2[i][e]);
-            }
+                for (int e = 0; e < 4; ++e) {
+                    all[i * 8 + e] = s1[i][e];
+                    all[i * 8 + 4 + e] = s2[i][e];
+                }
+            row16_sum_all(all);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[i][e] = all[i * 8 + e];
+                    s2[i][e] = all[i * 8 + 4 + e];
+                }
+        }
         if (r16 == 0) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
