@@ -61,6 +61,8 @@ _SIGS = {
     "bg_dwconv3x3_bwd_weight": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_fwd_pre": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_weight_pre": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "bg_dwconv3x3_fwd_pre_stats": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                   c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
     "bg_norm_stats": [c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "bg_norm_finalize": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                          c_vp],

@@ -22,6 +22,23 @@ struct DwParams {
     const float* pre_shift;
     int pre_act;
     int pre_ipg;  // images per statistic group
+    // ... or, with pre_sum set (dw_ring_kernel only), the fp64 sums of the producer's statistics epilogue: every block
+    // derives the affine of its image's group itself (bg_norm_finalize_affine's arithmetic, once per channel, through
+    // LDS) and the first block of each group publishes mean / rstd / scale / shift for the backward pass; the block of
+    // image 0 also applies the running-statistics update -- no finalize launch between the GEMM and this kernel
+    const double* pre_sum;
+    const double* pre_sumsq;
+    const float* pre_gamma;
+    const float* pre_beta;
+    float pre_eps, pre_mom;
+    float* pre_rmean;
+    float* pre_rvar;
+    float* pre_mean_out;
+    float* pre_rstd_out;
+    float* pre_scale_out;
+    float* pre_shift_out;
+    long long pre_rpg;  // rows (pixels) per statistic group
+    int pre_groups;
 };
 
 // Normalisation + activation of one loaded chunk, rounded to T exactly as bg_norm_act_fwd would have stored it (the
@@ -300,13 +317,54 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     int band, xblk;
     dw_block_to_row(P.bx, band, xblk);
     const unsigned idx = xblk * 256u + threadIdx.x;
+    const int n = band / P.bands, b = band - n * P.bands;
+    float* ptab = reinterpret_cast<float*>(dw_smem + DW_RING_LDS);  // [2][C] scale, shift (PRE with pre_sum)
+    if (PRE && P.pre_sum) {   // block-uniform
+        const int g = n / P.pre_ipg;
+        const bool publish = b == 0 && xblk == 0 && n == g * P.pre_ipg;  // first block of the group's first image
+        const double cnt = (double)P.pre_rpg, inv_n = 1.0 / cnt;
+        for (int ch = threadIdx.x; ch < P.C; ch += 256) {
+            const long long i = (long long)g * P.C + ch;
+            const double m = P.pre_sum[i] * inv_n;
+            double var = P.pre_sumsq[i] * inv_n - m * m;
+            if (var < 0.0 || P.pre_rpg == 1) var = 0.0;
+            const float r = rsqrtf((float)var + P.pre_eps);
+            float a, sh_;
+            const float gm = P.pre_gamma ? P.pre_gamma[ch] : 1.f, bt = P.pre_beta ? P.pre_beta[ch] : 0.f;
+            // norm_affine of norm_act.hip: the backward kernels re-form the affine this way from mean / rstd
+            a = gm * r;
+            sh_ = fmaf(-((float)m * gm), r, bt);
+            ptab[ch] = a;
+            ptab[P.C + ch] = sh_;
+            if (publish) {
+                P.pre_mean_out[i] = (float)m;
+                P.pre_rstd_out[i] = r;
+                P.pre_scale_out[i] = a;
+                P.pre_shift_out[i] = sh_;
+                if (P.pre_rmean && g == 0) {   // one momentum update per statistic group, in group order
+                    float rm = P.pre_rmean[ch], rv = P.pre_rvar[ch];
+                    for (int gg = 0; gg < P.pre_groups; ++gg) {
+                        const long long j = (long long)gg * P.C + ch;
+                        const double mg = P.pre_sum[j] * inv_n;
+                        double vg = P.pre_sumsq[j] * inv_n - mg * mg;
+                        if (vg < 0.0 || P.pre_rpg == 1) vg = 0.0;
+                        const double unb = P.pre_rpg > 1 ? vg * cnt / (cnt - 1.0) : vg;
+                        rm = (1.f - P.pre_mom) * rm + P.pre_mom * (float)mg;
+                        rv = (1.f - P.pre_mom) * rv + P.pre_mom * (float)unb;
+                    }
+                    P.pre_rmean[ch] = rm;
+                    P.pre_rvar[ch] = rv;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (idx >= (unsigned)P.items) return;
     const unsigned wq = idx / cv;
     const int c = (int)(idx - wq * cv) * VEC;
     const int D = P.dil;
     const int pc = (int)wq / P.wgroups, gi = (int)wq - pc * P.wgroups;  // column phase, group inside it
     const int wo0 = pc + gi * TW * D;
-    const int n = band / P.bands, b = band - n * P.bands;
     const int pr = b / P.bands_per_phase, bi = b - pr * P.bands_per_phase;  // row phase, band inside it
     const int ho0 = pr + bi * P.rb * D;
     const int ho1 = min(ho0 + P.rb * D, P.Ho);
@@ -330,10 +388,12 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     const float pslope = act_max_slope(P.pre_act);
     if (PRE) {
         const long long o = (long long)(n / P.pre_ipg) * P.C + c;
+        const float* tsc = P.pre_sum ? ptab + c : P.pre_scale + o;      // LDS table of this block / global table
+        const float* tsh = P.pre_sum ? ptab + P.C + c : P.pre_shift + o;
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(P.pre_scale + o + e);
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(P.pre_shift + o + e);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(tsc + e);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(tsh + e);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 psc[e + k] = a[k];
@@ -907,10 +967,11 @@ template <typename T, int FLIP, int PRE>
 void launch_dw_ring_t(const DwParams& P, unsigned blocks, hipStream_t st) {
     static const bool once = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_ring_kernel<T, FLIP, PRE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, DW_RING_LDS) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, DW_RING_LDS + 32 * 1024) == hipSuccess;
     }();
     (void)once;
-    hipLaunchKernelGGL((dw_ring_kernel<T, FLIP, PRE>), dim3(blocks), dim3(256), DW_RING_LDS, st, P);
+    const size_t lds = DW_RING_LDS + (PRE && P.pre_sum ? (size_t)2 * P.C * sizeof(float) : 0);
+    hipLaunchKernelGGL((dw_ring_kernel<T, FLIP, PRE>), dim3(blocks), dim3(256), lds, st, P);
 }
 
 // stride 1 / dilation 1 launcher shared by forward (flip 0) and data gradient (flip 1)
@@ -949,7 +1010,7 @@ int launch_dw_s1(int dtype, DwParams P, int flip, hipStream_t st, const char* wh
     const unsigned nb = (unsigned)blocks;
     if (ring) {
         if (flip) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 1, 0>(P, nb, st)));
-        else if (P.pre_scale) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 1>(P, nb, st)));
+        else if (P.pre_scale || P.pre_sum) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 1>(P, nb, st)));
         else BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 0>(P, nb, st)));
     } else {
         if (flip) BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((dw_s1_kernel<T, 1, 0>), dim3(nb), dim3(256), 0, st, P));
@@ -992,6 +1053,32 @@ extern "C" int bg_dwconv3x3_fwd_pre(const bg_dwconv_desc* d, const void* x, cons
     if (rc) return rc;
     return dw_fwd_impl(d, x, &pre, w, y, stream);
 }
+extern "C" int bg_dwconv3x3_fwd_pre_stats(const bg_dwconv_desc* d, const void* x, const double* sum, const double* sumsq,
+                                          const float* gamma, const float* beta, float eps, float momentum,
+                                          float* running_mean, float* running_var, float* mean, float* rstd,
+                                          float* scale, float* shift, int32_t groups, int32_t act, const void* w, void* y,
+                                          void* stream) {
+    int rc = check_dw(d, "bg_dwconv3x3_fwd_pre_stats");
+    if (rc) return rc;
+    BG_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "bg_dwconv3x3_fwd_pre_stats: null/unaligned pointer");
+    BG_CHECK_ARG(sum && sumsq && mean && rstd && scale && shift, "bg_dwconv3x3_fwd_pre_stats: null statistics pointer");
+    BG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bg_dwconv3x3_fwd_pre_stats: running statistics come in pairs");
+    BG_CHECK_ARG(groups >= 1 && d->N % groups == 0 && act >= 0 && act <= 2, "bg_dwconv3x3_fwd_pre_stats: bad groups / act");
+    BG_CHECK_ARG(d->stride == 1 && (d->dil == 1 || d->dil == 2), "bg_dwconv3x3_fwd_pre_stats: stride 1 with dilation 1 or 2 only");
+    BG_CHECK_ARG(d->C % 4 == 0 && (size_t)2 * d->C * sizeof(float) <= 32 * 1024, "bg_dwconv3x3_fwd_pre_stats: C = %d not supported", d->C);
+    static const bool ring = !(getenv("BGAMD_DW_RING") && atoi(getenv("BGAMD_DW_RING")) == 0);
+    BG_CHECK_ARG(ring, "bg_dwconv3x3_fwd_pre_stats needs the ring kernel (BGAMD_DW_RING=0 is set)");
+    DwParams P{x, w, y, d->N, d->H, d->W, d->C, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy, 0, 0};
+    P.pre_act = act;
+    P.pre_ipg = d->N / groups;
+    P.pre_sum = sum; P.pre_sumsq = sumsq; P.pre_gamma = gamma; P.pre_beta = beta; P.pre_eps = eps; P.pre_mom = momentum;
+    P.pre_rmean = running_mean; P.pre_rvar = running_var; P.pre_mean_out = mean; P.pre_rstd_out = rstd;
+    P.pre_scale_out = scale; P.pre_shift_out = shift;
+    P.pre_rpg = (long long)P.pre_ipg * d->H * d->W;
+    P.pre_groups = groups;
+    return launch_dw_s1(d->dtype, P, 0, (hipStream_t)stream, "dw_ring_kernel(pre, stats)");
+}
+
 extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw,
                                        void* stream) {
     return dw_bwd_weight_impl(d, x, nullptr, dy, dw, stream);

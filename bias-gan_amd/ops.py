@@ -590,6 +590,9 @@ class NormActFn(torch.autograd.Function):
         return (dx, dres) + (None,) * 15
 
 
+_FOLD_FINALIZE = _os.environ.get("BGAMD_NO_FOLD_FINALIZE") is None and _os.environ.get("BGAMD_DW_RING", "1") != "0"   # A/B switch
+
+
 class NormActDwConvFn(torch.autograd.Function):
     """dw3x3( act( BatchNorm2d_train(x) ) ): the [BatchNorm2d -> LeakyReLU -> SeparableConv2d_same.conv1] chain of the
     Xception units (deeplab.py:75-87, 90-143) with the activated tensor never written to memory.  The statistics are
@@ -616,13 +619,20 @@ class NormActDwConvFn(torch.autograd.Function):
             L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
         mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
         upd = rmean is not None
-        L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
-               arena.master_ptr(gslot), arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None,
-               rvar.data_ptr() if upd else None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
         y = new_act(n, h, w, c, x.dtype, dev)
         desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
-        L.call("bg_dwconv3x3_fwd_pre", desc, x.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, int(act),
-               arena.weight_ptr(wslot), y.data_ptr())
+        if _FOLD_FINALIZE and c <= 4096:
+            # the depthwise kernel finalises the statistics itself (no launch between the GEMM and it)
+            L.call("bg_dwconv3x3_fwd_pre_stats", desc, x.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot),
+                   arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None,
+                   mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, int(act),
+                   arena.weight_ptr(wslot), y.data_ptr())
+        else:
+            L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
+                   arena.master_ptr(gslot), arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None,
+                   rvar.data_ptr() if upd else None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            L.call("bg_dwconv3x3_fwd_pre", desc, x.data_ptr(), scale.data_ptr(), shift.data_ptr(), groups, int(act),
+                   arena.weight_ptr(wslot), y.data_ptr())
         ctx.save_for_backward(x, mean, rstd, scale, shift)
         ctx.meta = (arena, gslot, bslot, wslot, int(act), groups, dil)
         return y

@@ -144,6 +144,14 @@ int bg_dwconv3x3_fwd_pre(const bg_dwconv_desc* d, const void* x, const float* sc
                          int32_t groups, int32_t act, const void* w, void* y, void* stream);
 int bg_dwconv3x3_bwd_weight_pre(const bg_dwconv_desc* d, const void* x, const float* scale, const float* shift,
                                 int32_t groups, int32_t act, const void* dy, float* dw, void* stream);
+/* bg_norm_finalize_affine + bg_dwconv3x3_fwd_pre in ONE launch: sum / sumsq are the fp64 [groups, C] statistics of x
+ * (bg_conv2d_fwd_stats' epilogue or bg_norm_stats); every workgroup derives the affine of its image's group itself and
+ * the first workgroup of each group writes mean / rstd / scale / shift (fp32 [groups, C], needed by the backward
+ * kernels); running_* (may be NULL) get one momentum update per group, in group order.  Same bits as the two calls. */
+int bg_dwconv3x3_fwd_pre_stats(const bg_dwconv_desc* d, const void* x, const double* sum, const double* sumsq,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* mean, float* rstd, float* scale, float* shift, int32_t groups,
+                               int32_t act, const void* w, void* y, void* stream);
 
 /* ---------------------------------------------------------------------------
  * 3-D DeepLab GAN path (architecture/gpsro/deeplab3d.py).  A volume [N,D,H,W,C] is the

@@ -905,6 +905,18 @@ def test_dwconv_with_norm_act_prologue(case, dtype):
     assert torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
     assert_close(rm1.cpu(), rm0.cpu(), 1e-6, "running_mean")  # same formula; the compiler contracts the two copies differently
     assert_close(rv1.cpu(), rv0.cpu(), 1e-6, "running_var")
+    # ... and the one-launch form (finalize folded into the depthwise kernel's prologue)
+    rm2, rv2 = torch.full((cp,), 0.1, device=DEV), torch.full((cp,), 0.9, device=DEV)
+    mean2, rstd2, scale2, shift2 = f32(groups, cp), f32(groups, cp), f32(groups, cp), f32(groups, cp)
+    y2 = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_fwd_pre_stats", desc, xv.data_ptr(), s.data_ptr(), ss.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+           1e-5, 0.1, rm2.data_ptr(), rv2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(),
+           groups, act, wk.data_ptr(), y2[..., 8:].data_ptr())
+    assert torch.equal(mean2, mean1) and torch.equal(rstd2, rstd1)
+    assert torch.equal(scale2, scale) and torch.equal(shift2, shift)
+    assert_close(rm2.cpu(), rm1.cpu(), 1e-6, "running_mean (folded finalize)")
+    assert_close(rv2.cpu(), rv1.cpu(), 1e-6, "running_var (folded finalize)")
+    assert torch.equal(y2, y1), (y2.float() - y1.float()).abs().max().item()
     assert torch.equal(y0, y1), (y0.float() - y1.float()).abs().max().item()
     assert y0[..., 8:].float().abs().sum().item() > 0
     assert_close(dw1.cpu(), dw0.cpu(), 1e-5, "dw wgrad (fused prologue)")
