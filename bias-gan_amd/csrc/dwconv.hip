@@ -418,82 +418,74 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
 #pragma unroll
     for (int q = 0; q < PF; ++q)
         if (q < Q) issue_row(q, q);
-    Chunk<T> r0[NCOL], r1[NCOL], r2[NCOL];
+    // Scatter form: the new input row is unpacked ONCE and added into the three output rows it contributes to (taps
+    // 0-2 of output row q, 3-5 of row q-1, 6-8 of row q-2, which is complete afterwards and stored).  The gather form --
+    // three packed rows kept, all three unpacked again for every output row -- spent 144 of its 304 VALU instructions
+    // per row on those conversions, and with one workgroup per CU the kernel is VALU-bound (SQ: 71 % of wave cycles
+    // issuing).  The three accumulator rows rotate by renaming (the loop body is instantiated three times).
+    float wf[9][VEC];
 #pragma unroll
-    for (int j = 0; j < NCOL; ++j) {
-        r1[j].zero();
-        r2[j].zero();
-    }
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wf[t][e] = wv[t].get(e);
+    float acc0[TW][VEC], acc1[TW][VEC], acc2[TW][VEC];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc0[t][e] = acc1[t][e] = acc2[t][e] = 0.f;
     int slot = 0;
-    for (int q = 0; q < Q; ++q) {
+    auto consume = [&](int q, float (&aA)[TW][VEC], float (&aB)[TW][VEC], float (&aC)[TW][VEC]) {
         const int rem = Q - 1 - q;  // input rows after this one
         // younger operations than row q's six loads: steady state = this wave's 4 stores of iteration q-PF, then
         // (6 loads + 4 stores) of each of the PF-1 iterations since; otherwise count only the rows issued after q
         // (waiting for more than necessary is always safe)
-#if defined(DW_DBG_NOSTORE)
-        if (q >= PF + 2 && rem >= PF - 1) dw_wait_vmcnt<(PF - 1) * NCOL>();
-#else
         if (q >= PF + 2 && rem >= PF - 1) dw_wait_vmcnt<TW + (PF - 1) * (NCOL + TW)>();
-#endif
         else if (rem >= 2) dw_wait_vmcnt<2 * NCOL>();
         else if (rem == 1) dw_wait_vmcnt<NCOL>();
         else dw_wait_vmcnt<0>();
+        Chunk<T> row[NCOL];
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) {
-            r0[j] = r1[j];
-            r1[j] = r2[j];
-            r2[j].v = *reinterpret_cast<const vec_t*>(wb + (slot * NCOL + j) * 1024 + lane * 16);
-        }
+        for (int j = 0; j < NCOL; ++j) row[j].v = *reinterpret_cast<const vec_t*>(wb + (slot * NCOL + j) * 1024 + lane * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is read before the DMA below refills it
         if (q + PF < Q) issue_row(q + PF, slot);
         slot = slot + 1 == PF ? 0 : slot + 1;
         if (PRE) {
             const bool rok = (unsigned)(ho0 + (q - 1) * D) < (unsigned)P.H;
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) dw_pre_apply<T>(r2[j], psc, psh, pslope, rok && cok[j]);
+            for (int j = 0; j < NCOL; ++j) dw_pre_apply<T>(row[j], psc, psh, pslope, rok && cok[j]);
         }
-        if (q < 2) continue;
-        float acc[TW][VEC];
 #pragma unroll
-        for (int t = 0; t < TW; ++t)
+        for (int j = 0; j < NCOL; ++j) {
+            float xf[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
-#if defined(DW_DBG_NOCOMPUTE)  // timing experiment: the memory traffic without the arithmetic
+            for (int e = 0; e < VEC; ++e) xf[e] = row[j].get(e);
 #pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[t][e] = r1[t + 1].get(e) + r0[t].get(e) + r2[t + 2].get(e);
-#else
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < 3; ++s) {
+                const int t = j - s;   // output column (of this thread's four) that input column j feeds through tap s
+                if (t < 0 || t >= TW) continue;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    acc[t][e] = fmaf(r0[t + s].get(e), wv[0 + s].get(e), acc[t][e]);
-                    acc[t][e] = fmaf(r1[t + s].get(e), wv[3 + s].get(e), acc[t][e]);
-                    acc[t][e] = fmaf(r2[t + s].get(e), wv[6 + s].get(e), acc[t][e]);
+                    aC[t][e] = s == 0 ? xf[e] * wf[0][e] : fmaf(xf[e], wf[s][e], aC[t][e]);   // tap row 0 opens row q
+                    aB[t][e] = fmaf(xf[e], wf[3 + s][e], aB[t][e]);
+                    aA[t][e] = fmaf(xf[e], wf[6 + s][e], aA[t][e]);
                 }
-#endif
-#if defined(DW_DBG_NOSTORE)  // timing experiment: no stores issued (P.N is never negative)
-        if (P.N >= 0) {
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) sum += acc[t][e];
-            if (sum != 12345.678f) continue;
+            }
         }
-#endif
+        if (q < 2) return;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             yn + (long long)(ho0 + (q - 2) * D) * orow_bytes, 0, orow_bytes, 0x00020000);
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
             Chunk<T> o;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o.set(e, acc[t][e]);
+            for (int e = 0; e < VEC; ++e) o.set(e, aA[t][e]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.v), ro, goff[t], 0, 0);
         }
+    };
+    for (int q = 0; q < Q; q += 3) {
+        consume(q, acc0, acc1, acc2);
+        if (q + 1 < Q) consume(q + 1, acc1, acc2, acc0);
+        if (q + 2 < Q) consume(q + 2, acc2, acc0, acc1);
     }
 }
 
