@@ -119,6 +119,33 @@ def golden_generator(tag, c, h, w, n, seed, upsampler="Interpolate", grad_full=N
     print("generator", tag, "loss", loss.item())
 
 
+def golden_generator_crop(tag, c, h, w, n, seed, stride=8):
+    """The generator at a realistic field size (SURVEY section 7 stage 0: 256 x 256 x 16, N = 4), stored as a strided crop
+    of the output plus checksums of the full output and of every parameter gradient (the full tensors would be 4 MB +
+    220 MB)."""
+    g, spec = build_ref_generator(c, nn.BatchNorm2d, seed)
+    g.train()
+    x, y = orc.synthetic_fields(n, c, h, w, seed + 100)
+    out = g(x)
+    loss = (out - y).abs().mean()
+    loss.backward()
+    res = {"out_crop": out.detach()[:, :, ::stride, ::stride].contiguous().numpy(), "loss": np.array(loss.item()),
+           "out_cs": checksums([("out", out)])["out"]}
+    cs = checksums((k, p.grad) for k, p in g.named_parameters())
+    res["grad_keys"] = np.array(list(cs.keys()))
+    res["grad_cs"] = np.stack(list(cs.values()))
+    named = dict(g.named_parameters())
+    for k in GRAD_FULL_G:
+        res["grad::" + k] = named[k].grad.numpy()
+    sd = g.state_dict()
+    for k in ("model.xception_features.bn1.running_mean", "model.xception_features.bn1.running_var",
+              "model.global_avg_pool.2.running_var", "model.upsample.last_conv.4.running_mean"):
+        res["buf::" + k] = sd[k].numpy()
+    np.savez_compressed(os.path.join(HERE, f"generator_{tag}.npz"), meta=json.dumps(
+        dict(c=c, h=h, w=w, n=n, seed=seed, field_seed=seed + 100, stride=stride, upsampler="Interpolate")), **res)
+    print("generator (crop)", tag, "loss", loss.item())
+
+
 def golden_generator_noise(tag, c, nd, h, w, n, seed, noise_type="Uniform", noise_seed=77):
     """Generator with noise_dimensions > 0 -- the reference's default (train_gan.py:460): the noise is drawn on the HOST
     RNG stream by torch.distributions...rsample inside forward (deeplab_gan.py:85-90), so it is a function of
@@ -746,6 +773,8 @@ if __name__ == "__main__":
     if "all" in which or "gen" in which:
         golden_generator("c4_64x64", 4, 64, 64, 2, seed=1)
         golden_generator("c8_40x56", 8, 40, 56, 2, seed=2)
+    if "all" in which or "gen256" in which:
+        golden_generator_crop("c16_256x256", 16, 256, 256, 4, seed=12)
     if "all" in which or "gen_noise" in which:
         golden_generator_noise("nd1_c4_40x56", 4, 1, 40, 56, 2, seed=8)
         golden_generator_noise("nd2n_c4_40x56", 4, 2, 40, 56, 2, seed=9, noise_type="Normal")

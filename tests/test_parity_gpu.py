@@ -247,6 +247,61 @@ def test_generator_vs_reference_golden(golden_dir, tag, dtype):
     assert rms_err(oe.cpu(), z["out_eval"]) <= (5e-4 if dtype == F32 else 3e-1)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_generator_256x256x16_vs_reference_golden(golden_dir, dtype):
+    """The generator at 256 x 256 x 16, N = 4 (BASELINE config c2's shape; SURVEY section 7 stage 0) against the
+    reference: a stride-8 crop of the output, the checksums of the whole output, the loss, selected full parameter
+    gradients, the sum-of-squares checksum of every parameter gradient, running statistics.  fp32 path at the bounds
+    of the small goldens [measured: crop 2e-5, checksums 5e-7, gradients 6.7e-3 rms]; bf16 path at 2 x measured
+    (printed with -s)."""
+    z, m = gz(golden_dir, "generator_c16_256x256.npz")
+    G, spec = build_generator(m["c"], m["seed"], dtype)
+    G.train()
+    x, y = orc.synthetic_fields(m["n"], m["c"], m["h"], m["w"], m["field_seed"])
+    out = G(x.to(DEV))
+    st = m["stride"]
+    crop = out.detach()[:, :, ::st, ::st].cpu()
+    assert crop.shape == tuple(z["out_crop"].shape)
+    e, r = rel_err(crop, z["out_crop"]), rms_err(crop, z["out_crop"])
+    got_cs = cs(out)
+    cs_rel = np.abs(got_cs - z["out_cs"]) / (np.abs(z["out_cs"]) + 1e-30)
+    loss = losses.L1Loss()(out, y.to(DEV))
+    l_rel = abs(loss.item() - float(z["loss"])) / float(z["loss"])
+    print(f"generator 256x256x16 {dtype}: crop max-rel {e:.2e} rms-rel {r:.2e}; |out| / out^2 checksums rel "
+          f"{cs_rel[1]:.2e} {cs_rel[2]:.2e}; loss rel {l_rel:.2e}")
+    loss.backward()
+    named = dict(G.named_parameters())
+    worst_max = worst_rms = 0.0
+    for k in z.files:
+        if k.startswith("grad::"):
+            em, er = rel_err(named[k[6:]].grad.cpu(), z[k]), rms_err(named[k[6:]].grad.cpu(), z[k])
+            print(f"      {k[6:]:55s} max-rel {em:.2e} rms-rel {er:.2e}")
+            worst_max, worst_rms = max(worst_max, em), max(worst_rms, er)
+    ref = dict(zip([str(k) for k in z["grad_keys"]], z["grad_cs"]))
+    worst_sq = max(abs(cs(p.grad)[2] - ref[k][2]) / (ref[k][2] + 1e-30) for k, p in named.items())
+    print(f"   selected parameter grads worst max-rel {worst_max:.2e} rms-rel {worst_rms:.2e}; sum-of-squares of every "
+          f"parameter gradient worst rel {worst_sq:.2e}")
+    sd = G.state_dict()
+    worst_buf = max(rel_err(sd[k[5:]].cpu(), z[k]) for k in z.files if k.startswith("buf::"))
+    print(f"   running statistics worst rel {worst_buf:.2e}")
+    if dtype == F32:
+        assert e <= 2e-4 and r <= 1e-4 and cs_rel[1] <= 1e-4 and cs_rel[2] <= 1e-4 and l_rel <= 1e-5
+        assert worst_rms <= 3e-2 and worst_max <= 6e-2 and worst_sq <= 6e-2
+        assert worst_buf <= 1e-4
+    else:
+        # measured: crop rms-rel 1.02e-1, checksums 7.2e-4 / 2.6e-4, loss 1.5e-4, running statistics 8.5e-4; gradients of the
+        # parameters next to the output 4e-3 (last_conv.6.bias) .. 4.3e-2 (last_conv.6.weight) rms-rel; the gradients
+        # of the first layers, 140 bf16 layers (forward and back) away from the loss, are decorrelated from the fp32
+        # reference (rms-rel 0.7: the cascade of rounding-boundary and LeakyReLU-kink flips of this randomly filled
+        # net, see the module docstring) -- for those only the energy is bounded
+        assert r <= 2.1e-1 and cs_rel[1] <= 1.5e-3 and cs_rel[2] <= 6e-4 and l_rel <= 3.1e-4
+        for k, bound in (("model.upsample.last_conv.6.bias", 8e-3), ("model.upsample.last_conv.6.weight", 8.6e-2),
+                         ("model.bn2.weight", 5e-2)):
+            assert rms_err(named[k].grad.cpu(), z["grad::" + k]) <= bound, k
+        assert worst_sq <= 6.7e-1 and worst_buf <= 1.7e-3
+        assert all(torch.isfinite(p.grad).all() for p in named.values())
+
+
 @pytest.mark.parametrize("tag", ["nd1_c4_40x56", "nd2n_c4_40x56"])
 def test_generator_with_noise_vs_reference_golden(golden_dir, tag):
     """noise_dimensions > 0 -- the reference's default (train_gan.py:460): the noise comes off the HOST RNG stream
