@@ -664,38 +664,6 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
 // 8 x 72 x 48 pixels x 728 channels = 2 x 128 tiles of 384 x 216 -- one per CU -- where 256 x 128 tiles needed two
 // rounds for 1.27 rounds of work.  Staging: A rows [s*128 + wave*16, +16) and B rows likewise per slot s, so every
 // wave issues the same SA + SB pieces per K-step (uniform counted waits); B slots beyond the tile are dummies.
-template <typename T, int BKB, int MI, int NJ>
-__device__ __forceinline__ void mma_fat(const char* sA, const char* sB, int rowA, int rowB, int lane, f32x4 (&acc)[MI][NJ]) {
-    const int r16 = lane & 15, q = lane >> 4;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int ks = 0; ks < BKB / 64; ++ks) {
-            bf16x8 b[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q));
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + i * 16 + r16, ks * 4 + q));
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int kk = 0; kk < BKB / 16; ++kk) {
-            float b[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float*>(sB + lds_off<BKB>(rowB + j * 16 + r16, kk) + q * 4);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const float a = *reinterpret_cast<const float*>(sA + lds_off<BKB>(rowA + i * 16 + r16, kk) + q * 4);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-}
-
 // Epilogue of the fat tile.  A lane's accumulators are 4 consecutive channels of one pixel: stored as they stand, a
 // wave instruction writes sixteen 32-byte pieces of sixteen pixel rows, and the memory side sees every 128-byte line of
 // the output four times (measured with in-kernel stamps: 10 us of a 39 us launch for 40 MB; 16 us when the four pieces
