@@ -266,13 +266,22 @@ class Block(BGModule):
         a = inp
         if self.start_with_relu and not pre_activated:
             a = ops.leaky_relu(inp)
-        a_main, a_skip = ops.fork(a, 2)
         units = list(self.rep)
         i = 1 if self.start_with_relu else 0
-        h = a_main
+        dw_done = False  # h is already the depthwise output of the unit about to run (norm_act_dw / the fork below)
+        first = units[i] if i < len(units) else None
+        if isinstance(first, SeparableConv2d_same) and ops.fork_dw_ok(first.conv1):
+            # the Block's input feeds its first depthwise convolution and its skip path: one autograd node whose
+            # backward adds the skip path's gradient inside the depthwise data-gradient kernel
+            arena = self.arena()
+            h, a_skip = ops.ForkDwConv3x3Fn.apply(a, first.conv1.weight, arena, arena.by_param[id(first.conv1.weight)],
+                                                  first.conv1.dilation[0])
+            dw_done = True
+        else:
+            a_main, a_skip = ops.fork(a, 2)
+            h = a_main
         last_norm = None
         last_sep = None
-        dw_done = False  # h is already the depthwise output of the unit about to run (norm_act_dw)
         while i < len(units):
             u = units[i]
             if isinstance(u, SeparableConv2d_same):

@@ -39,6 +39,9 @@ struct DwParams {
     float* pre_shift_out;
     long long pre_rpg;  // rows (pixels) per statistic group
     int pre_groups;
+    // ADD = 1 (dw_ring_kernel, data gradient): y = conv(x) + add, add an [N, Ho, Wo, C] tensor of pixel stride ldadd
+    const void* add;
+    int ldadd;
 };
 
 // Normalisation + activation of one loaded chunk, rounded to T exactly as bg_norm_act_fwd would have stored it (the
@@ -306,11 +309,16 @@ __device__ __forceinline__ void dw_wait_vmcnt() {
 }
 constexpr int DW_PF = 3;                       // rows in flight per wave
 constexpr int DW_RING_LDS = 4 * DW_PF * 6 * 1024;  // 4 waves x PF slots x 6 columns x 1 KiB
+constexpr int DW_RING_LDS_ADD = 4 * DW_PF * 10 * 1024;  // ... x (6 + 4) columns: the addend's four pixels ride in the slot
 
-template <typename T, int FLIP, int PRE>
+// ADD = 1: the stored value is conv(x) + add (the data gradient of a Block's first depthwise convolution plus the
+// gradient that reaches the Block's input through the skip path: the sum autograd would form in a pass of its own).
+// The addend's four chunks of the output row that slot q completes travel through the same ring slot.
+template <typename T, int FLIP, int PRE, int ADD = 0>
 __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     constexpr int VEC = Elem<T>::VEC;
-    constexpr int TW = 4, NCOL = TW + 2, PF = DW_PF;
+    constexpr int TW = 4, NCOL = TW + 2, PF = DW_PF, NC = ADD ? NCOL + TW : NCOL;
+    constexpr int RING_LDS = ADD ? DW_RING_LDS_ADD : DW_RING_LDS;
     typedef typename Elem<T>::vec_t vec_t;
     extern __shared__ __align__(16) char dw_smem[];
     const unsigned cv = P.C / VEC;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     dw_block_to_row(P.bx, band, xblk);
     const unsigned idx = xblk * 256u + threadIdx.x;
     const int n = band / P.bands, b = band - n * P.bands;
-    float* ptab = reinterpret_cast<float*>(dw_smem + DW_RING_LDS);  // [2][C] scale, shift (PRE with pre_sum)
+    float* ptab = reinterpret_cast<float*>(dw_smem + RING_LDS);  // [2][C] scale, shift (PRE with pre_sum)
     if (PRE && P.pre_sum) {   // block-uniform
         const int g = n / P.pre_ipg;
         const bool publish = b == 0 && xblk == 0 && n == g * P.pre_ipg;  // first block of the group's first image
@@ -372,11 +380,16 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     const unsigned orow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
     const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * row_bytes;
     char* yn = reinterpret_cast<char*>(P.y) + (long long)n * P.Ho * orow_bytes;
-    int voff[NCOL], goff[TW];  // negative (left of the image) -> huge unsigned -> out of range -> 0 / dropped
+    int voff[NCOL], goff[TW], aoff[TW];  // negative (left of the image) -> huge unsigned -> out of range -> 0 / dropped
 #pragma unroll
     for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 + (j - 1) * D) * P.ldx + c) * (int)sizeof(T);
 #pragma unroll
-    for (int t = 0; t < TW; ++t) goff[t] = ((wo0 + t * D) * P.ldy + c) * (int)sizeof(T);
+    for (int t = 0; t < TW; ++t) {
+        goff[t] = ((wo0 + t * D) * P.ldy + c) * (int)sizeof(T);
+        aoff[t] = ADD ? ((wo0 + t * D) * P.ldadd + c) * (int)sizeof(T) : 0;
+    }
+    const unsigned arow_bytes = ADD ? (unsigned)P.Wo * P.ldadd * sizeof(T) : 0u;
+    const char* an = ADD ? reinterpret_cast<const char*>(P.add) + (long long)n * P.Ho * arow_bytes : nullptr;
     Chunk<T> wv[9];
     {
         const T* w = reinterpret_cast<const T*>(P.w) + c;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
         for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(wo0 + (j - 1) * D) < (unsigned)P.W;
     }
     const int lane = threadIdx.x & 63;
-    char* wb = dw_smem + (threadIdx.x >> 6) * (PF * NCOL * 1024);
+    char* wb = dw_smem + (threadIdx.x >> 6) * (PF * NC * 1024);
     const int nout = (ho1 - ho0 + D - 1) / D;  // output rows of this band (on its row phase)
     const int Q = nout + 2;                    // input rows q = 0 .. Q-1 at image row ho0 + (q-1) D
     auto issue_row = [&](int q, int slot) {
@@ -413,7 +426,15 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(xn + (long long)(ok ? ih : 0) * row_bytes), 0, ok ? row_bytes : 0u, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) dw_dma16(rs, wb + (slot * NCOL + j) * 1024, voff[j]);
+        for (int j = 0; j < NCOL; ++j) dw_dma16(rs, wb + (slot * NC + j) * 1024, voff[j]);
+        if (ADD) {   // the addend of output row ho0 + (q-2) D, the row this slot completes
+            const int oh = ho0 + (q - 2) * D;
+            const bool aok = q >= 2 && oh < ho1;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(an + (long long)(aok ? oh : 0) * arow_bytes), 0, aok ? arow_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) dw_dma16(ra, wb + (slot * NC + NCOL + t) * 1024, aoff[t]);
+        }
     };
 #pragma unroll
     for (int q = 0; q < PF; ++q)
@@ -439,13 +460,17 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
         // younger operations than row q's six loads: steady state = this wave's 4 stores of iteration q-PF, then
         // (6 loads + 4 stores) of each of the PF-1 iterations since; otherwise count only the rows issued after q
         // (waiting for more than necessary is always safe)
-        if (q >= PF + 2 && rem >= PF - 1) dw_wait_vmcnt<TW + (PF - 1) * (NCOL + TW)>();
-        else if (rem >= 2) dw_wait_vmcnt<2 * NCOL>();
-        else if (rem == 1) dw_wait_vmcnt<NCOL>();
+        if (q >= PF + 2 && rem >= PF - 1) dw_wait_vmcnt<TW + (PF - 1) * (NC + TW)>();
+        else if (rem >= 2) dw_wait_vmcnt<2 * NC>();
+        else if (rem == 1) dw_wait_vmcnt<NC>();
         else dw_wait_vmcnt<0>();
-        Chunk<T> row[NCOL];
+        Chunk<T> row[NCOL], av[TW];
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) row[j].v = *reinterpret_cast<const vec_t*>(wb + (slot * NCOL + j) * 1024 + lane * 16);
+        for (int j = 0; j < NCOL; ++j) row[j].v = *reinterpret_cast<const vec_t*>(wb + (slot * NC + j) * 1024 + lane * 16);
+        if (ADD) {
+#pragma unroll
+            for (int t = 0; t < TW; ++t) av[t].v = *reinterpret_cast<const vec_t*>(wb + (slot * NC + NCOL + t) * 1024 + lane * 16);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is read before the DMA below refills it
         if (q + PF < Q) issue_row(q + PF, slot);
         slot = slot + 1 == PF ? 0 : slot + 1;
@@ -478,7 +503,7 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
         for (int t = 0; t < TW; ++t) {
             Chunk<T> o;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o.set(e, aA[t][e]);
+            for (int e = 0; e < VEC; ++e) o.set(e, ADD ? aA[t][e] + av[t].get(e) : aA[t][e]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.v), ro, goff[t], 0, 0);
         }
     };
@@ -955,15 +980,16 @@ int check_dw(const bg_dwconv_desc* d, const char* who) {
     return BG_OK;
 }
 
-template <typename T, int FLIP, int PRE>
+template <typename T, int FLIP, int PRE, int ADD = 0>
 void launch_dw_ring_t(const DwParams& P, unsigned blocks, hipStream_t st) {
+    constexpr int RING = ADD ? DW_RING_LDS_ADD : DW_RING_LDS;
     static const bool once = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_ring_kernel<T, FLIP, PRE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, DW_RING_LDS + 32 * 1024) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_ring_kernel<T, FLIP, PRE, ADD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RING + 32 * 1024) == hipSuccess;
     }();
     (void)once;
-    const size_t lds = DW_RING_LDS + (PRE && P.pre_sum ? (size_t)2 * P.C * sizeof(float) : 0);
-    hipLaunchKernelGGL((dw_ring_kernel<T, FLIP, PRE>), dim3(blocks), dim3(256), lds, st, P);
+    const size_t lds = RING + (PRE && P.pre_sum ? (size_t)2 * P.C * sizeof(float) : 0);
+    hipLaunchKernelGGL((dw_ring_kernel<T, FLIP, PRE, ADD>), dim3(blocks), dim3(256), lds, st, P);
 }
 
 // stride 1 / dilation 1 launcher shared by forward (flip 0) and data gradient (flip 1)
@@ -1001,7 +1027,8 @@ int launch_dw_s1(int dtype, DwParams P, int flip, hipStream_t st, const char* wh
     BG_CHECK_ARG(blocks <= 0x7fffffffLL, "%s: grid too large", who);
     const unsigned nb = (unsigned)blocks;
     if (ring) {
-        if (flip) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 1, 0>(P, nb, st)));
+        if (flip && P.add) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 1, 0, 1>(P, nb, st)));
+        else if (flip) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 1, 0>(P, nb, st)));
         else if (P.pre_scale || P.pre_sum) BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 1>(P, nb, st)));
         else BG_DISPATCH_DTYPE(dtype, T, (launch_dw_ring_t<T, 0, 0>(P, nb, st)));
     } else {
@@ -1069,6 +1096,24 @@ extern "C" int bg_dwconv3x3_fwd_pre_stats(const bg_dwconv_desc* d, const void* x
     P.pre_rpg = (long long)P.pre_ipg * d->H * d->W;
     P.pre_groups = groups;
     return launch_dw_s1(d->dtype, P, 0, (hipStream_t)stream, "dw_ring_kernel(pre, stats)");
+}
+
+extern "C" int bg_dwconv3x3_bwd_data_add(const bg_dwconv_desc* d, const void* dy, const void* w, const void* add,
+                                         int32_t ldadd, void* dx, void* stream) {
+    int rc = check_dw(d, "bg_dwconv3x3_bwd_data_add");
+    if (rc) return rc;
+    BG_CHECK_ARG(dy && w && dx && add && aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(add),
+                 "bg_dwconv3x3_bwd_data_add: null/unaligned pointer");
+    BG_CHECK_ARG(d->stride == 1 && (d->dil == 1 || d->dil == 2), "bg_dwconv3x3_bwd_data_add: stride 1 with dilation 1 or 2 only");
+    BG_CHECK_ARG(ldadd >= d->C && ldadd % dtype_vec(d->dtype) == 0, "bg_dwconv3x3_bwd_data_add: bad pixel stride of the addend");
+    BG_CHECK_ARG((long long)d->W * ldadd * 4 < 0x7fffffffLL, "bg_dwconv3x3_bwd_data_add: image row too large");
+    static const bool ring = !(getenv("BGAMD_DW_RING") && atoi(getenv("BGAMD_DW_RING")) == 0);
+    BG_CHECK_ARG(ring, "bg_dwconv3x3_bwd_data_add needs the ring kernel (BGAMD_DW_RING=0 is set)");
+    // roles as in bg_dwconv3x3_bwd_data: dy plays the input (pixel stride ldy), dx the output (ldx); both H x W
+    DwParams Q{dy, w, dx, d->N, d->H, d->W, d->C, d->H, d->W, 1, d->dil, d->ldy, d->ldx, 0, 0};
+    Q.add = add;
+    Q.ldadd = ldadd;
+    return launch_dw_s1(d->dtype, Q, 1, (hipStream_t)stream, "dw_ring_kernel(flip, add)");
 }
 
 extern "C" int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw,

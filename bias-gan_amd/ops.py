@@ -464,6 +464,62 @@ class DwConv3x3Fn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+_FORK_DW = _os.environ.get("BGAMD_NO_FORK_DW") is None and _os.environ.get("BGAMD_DW_RING", "1") != "0"   # A/B switch
+
+
+class ForkDwConv3x3Fn(torch.autograd.Function):
+    """(dw3x3(x), x): a Block's input feeds its first depthwise convolution AND its skip path (deeplab.py:134-141).
+    Forward is DwConv3x3Fn plus an alias of x; backward forms the input gradient dwT(g_main) + g_skip in the depthwise
+    data-gradient kernel itself (bg_dwconv3x3_bwd_data_add) instead of a separate add pass over three tensors.
+    Stride 1, dilation 1 or 2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, dil):
+        x = nhwc(x)
+        n, h, w, c = x.shape
+        assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
+        y = new_act(n, h, w, c, x.dtype, x.device)
+        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
+        L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
+        if weight.requires_grad:
+            ctx.save_for_backward(x)
+        ctx.meta = (arena, wslot, dil, tuple(x.shape), x.dtype, x.device)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, gskip):
+        arena, wslot, dil, xshape, xdtype, xdev = ctx.meta
+        n, h, w, c = xshape
+        dt = L.dt(xdtype)
+        if g is not None:
+            g = nhwc(g)
+        if gskip is not None:
+            gskip = nhwc(gskip)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if g is None:
+                dx = gskip
+            else:
+                dx = new_act(n, h, w, c, xdtype, xdev)
+                desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(dx), ld_of(g))
+                if gskip is None:
+                    L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), dx.data_ptr())
+                else:
+                    L.call("bg_dwconv3x3_bwd_data_add", desc, g.data_ptr(), arena.weight_ptr(wslot), gskip.data_ptr(),
+                           ld_of(gskip), dx.data_ptr())
+        if ctx.needs_input_grad[1] and g is not None:
+            (x,) = ctx.saved_tensors
+            arena.ensure_grad(wslot)
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+            wgrad_call(xdev, (x, g), "bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
+        return dx, None, None, None, None
+
+
+def fork_dw_ok(conv1) -> bool:
+    """Can ForkDwConv3x3Fn run this depthwise convolution (stride 1, dilation 1 or 2, no bias)?"""
+    return _FORK_DW and conv1.stride[0] == 1 and conv1.dilation[0] in (1, 2) and conv1.bias is None
+
+
 # ------------------------------------------------------- norm + residual + LeakyReLU
 _BN_GROUPS = [1]
 

@@ -133,6 +133,11 @@ typedef struct bg_dwconv_desc {
 int bg_dwconv3x3_fwd(const bg_dwconv_desc* d, const void* x, const void* w, void* y, void* stream);
 int bg_dwconv3x3_bwd_data(const bg_dwconv_desc* d, const void* dy, const void* w, void* dx, void* stream);
 int bg_dwconv3x3_bwd_weight(const bg_dwconv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+/* dx = bg_dwconv3x3_bwd_data(dy) + add in one pass: the gradient at a Block's input is the data gradient of its first
+ * depthwise convolution plus the gradient arriving through the skip path (deeplab.py:134-141; autograd would form the
+ * sum in a pass of its own).  add: [N, H, W, C] of pixel stride ldadd; dx may alias add.  Stride 1, dilation 1 or 2. */
+int bg_dwconv3x3_bwd_data_add(const bg_dwconv_desc* d, const void* dy, const void* w, const void* add, int32_t ldadd,
+                              void* dx, void* stream);
 /* The same two kernels with the producer's normalisation + activation applied to every loaded input chunk:
  * the depthwise convolution (and its weight gradient) of act(x*scale[g,c] + shift[g,c]) where x is the RAW output
  * of the previous pointwise convolution -- the activated tensor of the reference's

@@ -932,6 +932,37 @@ def test_dwconv_with_norm_act_prologue(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 13, 18, 16, 1), (1, 9, 7, 728, 1), (2, 16, 12, 24, 2), (2, 11, 50, 264, 1), (8, 30, 20, 40, 1)])
+def test_dwconv_bwd_data_plus_addend(case, dtype):
+    """bg_dwconv3x3_bwd_data_add (data gradient + the skip path's gradient in one pass) against bg_dwconv3x3_bwd_data
+    followed by an fp32 add of the stored result and the addend, both against torch; in place (dx aliasing the addend)
+    gives the same bits."""
+    n, h, w, c, d = case
+    cp = up(c, dtype)
+    wt = rnd((c, 1, 3, 3), 82, dtype, 0.3)
+    go, ad = rnd((n, c, h, w), 83, dtype), rnd((n, c, h, w), 84, dtype)
+    ld = cp + 8
+    (gb, gv), (ab, av) = to_nhwc(go, dtype, ld, 8), to_nhwc(ad, dtype, ld, 8)
+    wk = torch.zeros(3, 3, cp, dtype=dtype, device=DEV)
+    wk[:, :, :c] = wt[:, 0].permute(1, 2, 0).to(dtype).to(DEV)
+    desc = L.DwDesc(L.dt(dtype), n, h, w, cp, h, w, 1, d, ld, ld)
+    dx1 = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_bwd_data_add", desc, gv.data_ptr(), wk.data_ptr(), av.data_ptr(), ld, dx1[..., 8:].data_ptr())
+    xr = torch.zeros(n, c, h, w, requires_grad=True)
+    F.conv2d(F.pad(xr, (d, d, d, d)), wt, None, 1, 0, d, groups=c).backward(go)
+    assert_close(from_nhwc(dx1[..., 8:], c), xr.grad + ad, tol(dtype), "dw bwd_data + addend vs torch")
+    dx0 = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_bwd_data", desc, gv.data_ptr(), wk.data_ptr(), dx0[..., 8:].data_ptr())
+    two_pass = (dx0[..., 8:].float() + av.float()).to(dtype)
+    # the fused kernel adds before rounding: at most one unit in the last place of the storage type apart
+    assert_close(dx1[..., 8:].float().cpu(), two_pass.float().cpu(), 1e-6 if dtype == torch.float32 else 8e-3, "fused vs two passes")
+    ab2 = ab.clone()
+    L.call("bg_dwconv3x3_bwd_data_add", desc, gv.data_ptr(), wk.data_ptr(), ab2[..., 8:].data_ptr(), ld, ab2[..., 8:].data_ptr())
+    assert torch.equal(ab2[..., 8:], dx1[..., 8:])
+    assert torch.equal(ab2[..., :8], ab[..., :8])   # the neighbouring channel slice is untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("p", [0, 1])
 def test_avgpool2x2(dtype, p):
     """bg_avgpool2x2 forward and adjoint vs F.avg_pool2d(2, 1, p) (count_include_pad default)."""

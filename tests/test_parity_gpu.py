@@ -112,6 +112,7 @@ def test_block_norm_inside_depthwise_matches_separate_passes(golden_dir, tag, dt
     out = {}
     for fused in (False, True):
         monkeypatch.setattr(dl, "_FUSED_DW", fused)
+        monkeypatch.setattr(ops, "_FORK_DW", fused)   # ... and the skip path's gradient added inside the depthwise data gradient
         calls = []
         orig = ops.NormActDwConvFn.apply
         monkeypatch.setattr(ops.NormActDwConvFn, "apply", lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
@@ -134,7 +135,8 @@ def test_block_norm_inside_depthwise_matches_separate_passes(golden_dir, tag, dt
     assert torch.equal(a[0], b[0])
     for k in a[3]:
         assert rel_err(b[3][k], a[3][k]) <= 1e-6, k
-    assert rel_err(b[1], a[1]) <= 1e-5
+    # input gradient: the fused fork adds the skip gradient BEFORE rounding dA to the storage type (one ulp in bf16)
+    assert rel_err(b[1], a[1]) <= (1e-5 if dtype == F32 else 8e-3)
     for k in a[2]:
         assert rel_err(b[2][k], a[2][k]) <= 2e-5, k
 
