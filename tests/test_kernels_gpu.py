@@ -173,7 +173,9 @@ def test_conv_mfma_layout_asymmetric(dtype):
 
 
 DW_CASES = [(2, 13, 18, 16, 1, 1), (2, 12, 10, 24, 2, 1), (1, 9, 7, 728, 1, 1), (2, 9, 7, 40, 1, 2), (1, 7, 5, 8, 2, 1),
-            (2, 16, 12, 24, 1, 2), (2, 11, 13, 40, 2, 1), (1, 20, 18, 264, 2, 1)]
+            (2, 16, 12, 24, 1, 2), (2, 11, 13, 40, 2, 1), (1, 20, 18, 264, 2, 1),
+            # the tiny maps at the bottom of a 64 x 64 discriminator: one- and two-row bands, fewer rows than taps
+            (4, 4, 4, 728, 1, 1), (4, 4, 4, 728, 1, 2), (2, 2, 3, 24, 1, 1), (3, 1, 5, 16, 1, 1), (2, 3, 2, 16, 1, 2)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
