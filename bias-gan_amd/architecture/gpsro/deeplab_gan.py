@@ -63,9 +63,16 @@ class Discriminator(BGModule):
 
     def forward(self, input):
         dt = self.compute_dtype()
-        n, c, H, W = input.shape
-        assert c == self.n_input, f"expected {self.n_input} input channels, got {c}"
-        xi = ops.ToInternal.apply(input, pad_to(c, vec_of(dt)), dt)
+        if isinstance(input, (tuple, list)):
+            # several batches pushed through as one (the trainer's D(real) + D(fake) pass): converted straight into the
+            # batch slices of one internal buffer instead of torch.cat + one conversion
+            n, c, H, W = sum(t.shape[0] for t in input), *input[0].shape[1:]
+            assert c == self.n_input, f"expected {self.n_input} input channels, got {c}"
+            xi = ops.ToInternalCat.apply(pad_to(c, vec_of(dt)), dt, *input)
+        else:
+            n, c, H, W = input.shape
+            assert c == self.n_input, f"expected {self.n_input} input channels, got {c}"
+            xi = ops.ToInternal.apply(input, pad_to(c, vec_of(dt)), dt)
         f, _ = self.xception_features.forward_nhwc(xi, want_low=False)
         a = self.arena()
         lin = self.linear

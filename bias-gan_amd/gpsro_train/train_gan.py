@@ -78,7 +78,7 @@ class GANTrainer:
                     with torch.cuda.stream(self._side):
                         self._g_ahead = (inputs, self.generator(inputs))
             with ops.batch_groups(2):               # group 0 = real, group 1 = fake: the reference's call order
-                logits, _ = self.discriminator(torch.cat((outputs_real, outputs_fake), dim=0))
+                logits, _ = self.discriminator((outputs_real, outputs_fake))
             return self._d_update(logits[:n], logits[n:], outputs_fake, outputs_real, labels, eta)
         if self._side == "auto":
             self._side = torch.cuda.Stream(device=inputs.device) if inputs.is_cuda else None

@@ -141,6 +141,25 @@ def test_block_norm_inside_depthwise_matches_separate_passes(golden_dir, tag, dt
         assert rel_err(b[2][k], a[2][k]) <= 2e-5, k
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_to_internal_cat_is_cat_then_convert(dtype):
+    """ops.ToInternalCat (the D-step's real + fake batch converted straight into one NHWC buffer) against
+    ToInternal(torch.cat(...)): identical bits forward, identical gradients to every input that wants one."""
+    torch.manual_seed(3)
+    a = torch.randn(3, 6, 9, 7, device=DEV, requires_grad=True)
+    b = torch.randn(2, 6, 9, 7, device=DEV)           # no gradient wanted (the detached fake batch)
+    c2 = torch.randn(1, 6, 9, 7, device=DEV, requires_grad=True)
+    cp = pad_to(6, vec_of(dtype))
+    y1 = ops.ToInternalCat.apply(cp, dtype, a, b, c2)
+    a2, c3 = a.detach().clone().requires_grad_(True), c2.detach().clone().requires_grad_(True)
+    y0 = ops.ToInternal.apply(torch.cat((a2, b, c3), dim=0), cp, dtype)
+    assert y1.shape == y0.shape and torch.equal(y1, y0)
+    g = torch.randn_like(y0.float()).to(dtype)
+    y1.backward(g)
+    y0.backward(g)
+    assert torch.equal(a.grad, a2.grad) and torch.equal(c2.grad, c3.grad) and b.grad is None
+
+
 def build_generator(c, seed, dtype, norm=nn.BatchNorm2d, upsampler="Interpolate"):
     spec = orc.generator_spec(c, c, 0, "batch", upsampler=upsampler)
     G = dxg.Generator(c, c, upsampler, "Uniform", 0, normalizer=norm, compute_dtype=dtype)
