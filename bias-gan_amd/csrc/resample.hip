@@ -25,57 +25,71 @@ struct RsParams {
     float rh, rw;
 };
 
-template <typename TI, typename TO>
-__global__ void resize_fwd_kernel(RsParams P) {
-    constexpr int V = 4;  // 4 channels per thread (16 B of f32 / 8 B of bf16): works for both dtypes
-    const int cv = P.C / V;
-    const long long total = (long long)P.N * P.Ho * P.Wo * cv;
-    const TI* x = reinterpret_cast<const TI*>(P.x);
-    TO* y = reinterpret_cast<TO*>(P.y);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * V;
-        long long t = i / cv;
-        const int wo = (int)(t % P.Wo);
-        t /= P.Wo;
-        const int ho = (int)(t % P.Ho);
-        const int n = (int)(t / P.Ho);
-        int h0, h1, w0, w1;
-        float lh0, lh1, lw0, lw1;
-        src_index(ho, P.rh, P.Hi, h0, h1, lh0, lh1);
-        src_index(wo, P.rw, P.Wi, w0, w1, lw0, lw1);
-        const TI* b = x + (long long)n * P.Hi * P.Wi * P.ldx + c;
-        const TI* p00 = b + ((long long)h0 * P.Wi + w0) * P.ldx;
-        const TI* p01 = b + ((long long)h0 * P.Wi + w1) * P.ldx;
-        const TI* p10 = b + ((long long)h1 * P.Wi + w0) * P.ldx;
-        const TI* p11 = b + ((long long)h1 * P.Wi + w1) * P.ldx;
-        TO* o = y + (((long long)n * P.Ho + ho) * P.Wo + wo) * P.ldy + c;
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float v = lh0 * (lw0 * Elem<TI>::to_f(p00[e]) + lw1 * Elem<TI>::to_f(p01[e])) +
-                            lh1 * (lw0 * Elem<TI>::to_f(p10[e]) + lw1 * Elem<TI>::to_f(p11[e]));
-            o[e] = Elem<TO>::from_f(v);
-        }
+// 4 channels of T as one 16-byte (f32) / 8-byte (bf16) access
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    typedef f32x4 vec;
+    __device__ static inline void load(const float* p, float (&v)[4]) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
     }
+    __device__ static inline void store(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Quad<bf16_t> {
+    __device__ static inline void load(const bf16_t* p, float (&v)[4]) {
+        const bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+    }
+    __device__ static inline void store(bf16_t* p, const float (&v)[4]) {
+        *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    }
+};
+
+// grid: one 1-D range of (output row, 256-item segment of the row's Wo * C/4 items): the row decomposition is one
+// scalar 32-bit division per block, the per-thread one a 32-bit division by C/4 -- the flat 64-bit index of the first
+// version cost three 64-bit divisions per item and held the kernel at 1.7 TB/s.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(RsParams P) {
+    constexpr int V = 4;
+    const unsigned cv = P.C / V;
+    const unsigned items = (unsigned)P.Wo * cv, segs = (items + 255u) / 256u;
+    const unsigned row = blockIdx.x / segs, seg = blockIdx.x - row * segs;   // row = n * Ho + ho
+    const unsigned it = seg * 256u + threadIdx.x;
+    if (it >= items) return;
+    const unsigned wo = it / cv;
+    const int c = (int)(it - wo * cv) * V;
+    const unsigned n = row / (unsigned)P.Ho, ho = row - n * (unsigned)P.Ho;
+    int h0, h1, w0, w1;
+    float lh0, lh1, lw0, lw1;
+    src_index((int)ho, P.rh, P.Hi, h0, h1, lh0, lh1);
+    src_index((int)wo, P.rw, P.Wi, w0, w1, lw0, lw1);
+    const TI* b = reinterpret_cast<const TI*>(P.x) + (long long)n * P.Hi * P.Wi * P.ldx + c;
+    float v00[4], v01[4], v10[4], v11[4], o[4];
+    Quad<TI>::load(b + ((long long)h0 * P.Wi + w0) * P.ldx, v00);
+    Quad<TI>::load(b + ((long long)h0 * P.Wi + w1) * P.ldx, v01);
+    Quad<TI>::load(b + ((long long)h1 * P.Wi + w0) * P.ldx, v10);
+    Quad<TI>::load(b + ((long long)h1 * P.Wi + w1) * P.ldx, v11);
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
+    Quad<TO>::store(reinterpret_cast<TO*>(P.y) + ((long long)row * P.Wo + wo) * P.ldy + c, o);
 }
 
 // Adjoint as a gather: every source pixel collects from the output pixels whose
 // forward stencil touches it, using the SAME fp32 index arithmetic as forward.
 template <typename TG, typename TX>
-__global__ void resize_bwd_kernel(RsParams P /* x = dy [Ho,Wo], y = dx [Hi,Wi] */) {
+__global__ __launch_bounds__(256) void resize_bwd_kernel(RsParams P /* x = dy [Ho,Wo], y = dx [Hi,Wi] */) {
     constexpr int V = 4;
-    const int cv = P.C / V;
-    const long long total = (long long)P.N * P.Hi * P.Wi * cv;
+    const unsigned cv = P.C / V;
     const TG* dy = reinterpret_cast<const TG*>(P.x);
     TX* dx = reinterpret_cast<TX*>(P.y);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * V;
-        long long t = i / cv;
-        const int wi = (int)(t % P.Wi);
-        t /= P.Wi;
-        const int hi = (int)(t % P.Hi);
-        const int n = (int)(t / P.Hi);
+    const unsigned items = (unsigned)P.Wi * cv, segs = (items + 255u) / 256u;   // grid as in resize_fwd_kernel, over dx rows
+    const unsigned row = blockIdx.x / segs, seg = blockIdx.x - row * segs;
+    const unsigned it = seg * 256u + threadIdx.x;
+    if (it >= items) return;
+    {
+        const int wi = (int)(it / cv);
+        const int c = (int)(it - (unsigned)wi * cv) * V;
+        const int n = (int)(row / (unsigned)P.Hi), hi = (int)(row - (unsigned)n * (unsigned)P.Hi);
         // candidate output rows: those whose source coordinate lies in (hi-1, hi+1)
         int ho_lo = 0, ho_hi = P.Ho - 1, wo_lo = 0, wo_hi = P.Wo - 1;
         if (P.rh > 0.f) {
@@ -107,15 +121,14 @@ __global__ void resize_bwd_kernel(RsParams P /* x = dy [Ho,Wo], y = dx [Hi,Wi] *
                 if (w0 == wi) ww += lw0;
                 if (w1 == wi) ww += lw1;
                 if (ww == 0.f) continue;
-                const TG* g = dy + (((long long)n * P.Ho + ho) * P.Wo + wo) * P.ldx + c;
+                float g[4];
+                Quad<TG>::load(dy + (((long long)n * P.Ho + ho) * P.Wo + wo) * P.ldx + c, g);
                 const float f = wh * ww;
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] = fmaf(f, Elem<TG>::to_f(g[e]), acc[e]);
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(f, g[e], acc[e]);
             }
         }
-        TX* o = dx + (((long long)n * P.Hi + hi) * P.Wi + wi) * P.ldy + c;
-#pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = Elem<TX>::from_f(acc[e]);
+        Quad<TX>::store(dx + (((long long)n * P.Hi + hi) * P.Wi + wi) * P.ldy + c, acc);
     }
 }
 
@@ -338,6 +351,8 @@ int check_rs(int dt_a, int dt_b, const void* a, int lda, void* b, int ldb, int N
     BG_CHECK_ARG(dtype_ok(dt_a) && dtype_ok(dt_b), "%s: bad dtype", who);
     BG_CHECK_ARG(a && b && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "%s: bad args", who);
     BG_CHECK_ARG(C % 4 == 0 && lda >= C && ldb >= C && lda % 4 == 0 && ldb % 4 == 0, "%s: C/ld must be multiples of 4", who);
+    BG_CHECK_ARG(((uintptr_t)a % (dt_a == BG_BF16 ? 8 : 16)) == 0 && ((uintptr_t)b % (dt_b == BG_BF16 ? 8 : 16)) == 0,
+                 "%s: pointers must be aligned to four channels", who);
     return BG_OK;
 }
 
@@ -357,8 +372,9 @@ extern "C" int bg_resize_bilinear_fwd(int32_t in_dtype, int32_t out_dtype, const
     int rc = check_rs(in_dtype, out_dtype, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, "bg_resize_bilinear_fwd");
     if (rc) return rc;
     RsParams P{x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, ac_ratio(Hi, Ho), ac_ratio(Wi, Wo)};
-    const long long total = (long long)N * Ho * Wo * (C / 4);
-    RS_DISPATCH(in_dtype, out_dtype, resize_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, P);
+    const long long blocks = (long long)N * Ho * (((long long)Wo * (C / 4) + 255) / 256);
+    BG_CHECK_ARG(blocks <= 0x7fffffffLL && (long long)Wo * (C / 4) < 0x7fffffffLL, "bg_resize_bilinear_fwd: grid too large");
+    RS_DISPATCH(in_dtype, out_dtype, resize_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     BG_CHECK_LAUNCH("resize_fwd_kernel");
     return BG_OK;
 }
@@ -369,8 +385,9 @@ extern "C" int bg_resize_bilinear_bwd(int32_t dy_dtype, int32_t dx_dtype, const 
     int rc = check_rs(dy_dtype, dx_dtype, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, "bg_resize_bilinear_bwd");
     if (rc) return rc;
     RsParams P{dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, ac_ratio(Hi, Ho), ac_ratio(Wi, Wo)};
-    const long long total = (long long)N * Hi * Wi * (C / 4);
-    RS_DISPATCH(dy_dtype, dx_dtype, resize_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, P);
+    const long long blocks = (long long)N * Hi * (((long long)Wi * (C / 4) + 255) / 256);
+    BG_CHECK_ARG(blocks <= 0x7fffffffLL && (long long)Wi * (C / 4) < 0x7fffffffLL, "bg_resize_bilinear_bwd: grid too large");
+    RS_DISPATCH(dy_dtype, dx_dtype, resize_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     BG_CHECK_LAUNCH("resize_bwd_kernel");
     return BG_OK;
 }
