@@ -153,16 +153,24 @@ __global__ void broadcast_rows_kernel(const float* v, float scale, T* y, int ldy
 template <typename TS, typename TD>
 __global__ void cast_rows_kernel(const TS* src, int lds, TD* dst, int ldd, long long rows, int C) {
     constexpr int V = 4;
-    const int cv = C / V;
+    const unsigned cv = C / V;
     const long long total = rows * cv;
+    // (32-bit row / channel split whenever the item index fits: the 64-bit pair cost more than the copy)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * V;
-        const long long row = i / cv;
-        const TS* s = src + row * lds + c;
-        TD* d = dst + row * ldd + c;
-#pragma unroll
-        for (int e = 0; e < V; ++e) d[e] = Elem<TD>::from_f(Elem<TS>::to_f(s[e]));
+        long long row;
+        int c;
+        if (total <= 0x7fffffffLL) {
+            const unsigned r = (unsigned)i / cv;
+            row = r;
+            c = (int)((unsigned)i - r * cv) * V;
+        } else {
+            row = i / cv;
+            c = (int)(i - row * cv) * V;
+        }
+        float v[4];
+        Quad<TS>::load(src + row * lds + c, v);
+        Quad<TD>::store(dst + row * ldd + c, v);
     }
 }
 
@@ -408,7 +416,9 @@ extern "C" int bg_broadcast_rows(int32_t dtype, const float* v, float scale, voi
 extern "C" int bg_cast_rows(int32_t src_dtype, int32_t dst_dtype, const void* src, int32_t lds, void* dst, int32_t ldd,
                             int64_t rows, int32_t C, void* stream) {
     BG_CHECK_ARG(dtype_ok(src_dtype) && dtype_ok(dst_dtype) && src && dst && rows > 0 && C > 0, "bg_cast_rows: bad args");
-    BG_CHECK_ARG(C % 4 == 0 && lds >= C && ldd >= C, "bg_cast_rows: C must be a multiple of 4, ld >= C");
+    BG_CHECK_ARG(C % 4 == 0 && lds >= C && ldd >= C && lds % 4 == 0 && ldd % 4 == 0, "bg_cast_rows: C and ld must be multiples of 4, ld >= C");
+    BG_CHECK_ARG(((uintptr_t)src % (src_dtype == BG_BF16 ? 8 : 16)) == 0 && ((uintptr_t)dst % (dst_dtype == BG_BF16 ? 8 : 16)) == 0,
+                 "bg_cast_rows: pointers must be aligned to four channels");
     const long long total = rows * (C / 4);
 #define CAST_ARGS(TS, TD) dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const TS*)src, lds, (TD*)dst, ldd, (long long)rows, C
     if (src_dtype == BG_BF16 && dst_dtype == BG_BF16) hipLaunchKernelGGL((cast_rows_kernel<bf16_t, bf16_t>), CAST_ARGS(bf16_t, bf16_t));
