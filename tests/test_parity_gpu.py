@@ -112,7 +112,8 @@ def test_block_norm_inside_depthwise_matches_separate_passes(golden_dir, tag, dt
     out = {}
     for fused in (False, True):
         monkeypatch.setattr(dl, "_FUSED_DW", fused)
-        monkeypatch.setattr(ops, "_FORK_DW", fused)   # ... and the skip path's gradient added inside the depthwise data gradient
+        # ... and the skip path's gradient added inside the depthwise data gradient (a ring-kernel entry point)
+        monkeypatch.setattr(ops, "_FORK_DW", fused and os.environ.get("BGAMD_DW_RING", "1") != "0")
         calls = []
         orig = ops.NormActDwConvFn.apply
         monkeypatch.setattr(ops.NormActDwConvFn, "apply", lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
