@@ -843,11 +843,18 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
                 const bf16x4 ov = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                 *reinterpret_cast<bf16x4*>(region + wr_off + i * 16 * ES) = ov;
                 if (stats) {
+                    // the stored values back as fp32 straight from the two packed dwords (one shift / one mask per
+                    // value instead of a conversion and a shift), accumulated as pairs (v_pk_add_f32 / v_pk_fma_f32)
+                    typedef __attribute__((ext_vector_type(2))) float f32x2;
+                    const u32x2 pk = __builtin_bit_cast(u32x2, ov);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float r = (float)ov[e];
-                        s1[i][e] += r;
-                        s2[i][e] = fmaf(r, r, s2[i][e]);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 r = {__uint_as_float(pk[h] << 16), __uint_as_float(pk[h] & 0xffff0000u)};
+                        f32x2 a1 = {s1[i][2 * h], s1[i][2 * h + 1]}, a2 = {s2[i][2 * h], s2[i][2 * h + 1]};
+                        a1 += r;
+                        a2 = r * r + a2;
+                        s1[i][2 * h] = a1[0]; s1[i][2 * h + 1] = a1[1];
+                        s2[i][2 * h] = a2[0]; s2[i][2 * h + 1] = a2[1];
                     }
                 }
             } else {
