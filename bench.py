@@ -145,7 +145,16 @@ class RingFeed:
         self.sample_bytes = os.path.getsize(self.sets[0][0])
         self.turn = 0
         self.bytes = 0
+        import atexit
+        atexit.register(self.close)      # ~1.8 GB of .npy files per rank at 1152x768x16, batch 8
         self._submit()
+
+    def close(self):
+        import shutil
+        d, self.dir = self.dir, None
+        if d:
+            self.reader = None
+            shutil.rmtree(d, ignore_errors=True)
 
     def _submit(self):
         for f in self.sets[self.turn % len(self.sets)]:
@@ -213,6 +222,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched plainly (`python bench.py --gpus N`): this parent never touches the GPU; it starts the N ranks as
+        # children of torch.distributed.run (one process per GPU over RCCL) and relays rank 0's JSON line and the exit
+        # code -- the reference's launcher contract (comm/distributed.py:195-199 expects one process per device).
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] no launcher environment: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+        if os.environ.get("BGAMD_BENCH_LAUNCH_ECHO"):      # tests/test_host_cpu.py: show the child command, start nothing
+            print(json.dumps(cmd))
+            raise SystemExit(0)
+        raise SystemExit(subprocess.run(cmd).returncode)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")

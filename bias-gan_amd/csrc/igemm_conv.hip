@@ -1888,6 +1888,11 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
             if (pw1) return launch_fat<T, 128, 4, 7, 4, 2, 2, true>(P, nblk, st);
             return launch_fat<T, 128, 4, 7, 4, 2, 2, false>(P, nblk, st);
         }
+        if (big) {   // the kernels below address the whole activation with 32-bit offsets
+            bg_set_error("conv: operand beyond 2 GiB and no fat-tile plan (statistic groups must divide the pixels; "
+                         "pixels per group < 2^31)");
+            return BG_E_ARG;
+        }
     }
     if (splits > 1) {   // split-K (few tiles, long reduction): 128 x 128 tiles, (tiles x splits) blocks, one workspace slice each
         const int kt_all = P.KH * P.KW * ((P.CK + 64 / (int)sizeof(T) - 1) / (64 / (int)sizeof(T)));
@@ -2185,6 +2190,9 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
     BG_CHECK_ARG(dtype == BG_BF16, "bg_conv2d_bwd_weight_grouped: bf16 operands only (the transposing LDS reads)");
     BG_CHECK_ARG(tbl && n_layers >= 1 && M >= 1 && M < (1LL << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 &&
                  ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, "bg_conv2d_bwd_weight_grouped: bad arguments");
+    // the kernel addresses a layer's operands with 32-bit byte offsets into per-layer descriptors
+    BG_CHECK_ARG((M - 1) * (long long)ldx * 2 + (long long)Cin * 2 < (1LL << 31) && (M - 1) * (long long)ldy * 2 + (long long)Cout * 2 < (1LL << 31),
+                 "bg_conv2d_bwd_weight_grouped: an operand beyond 2 GiB (M=%lld ldx=%d ldy=%d)", (long long)M, ldx, ldy);
     static const int nbuf = getenv("BGAMD_WGG_NBUF") ? atoi(getenv("BGAMD_WGG_NBUF")) : 4;   // 4 or 5 stages of 32 KiB (measured: 5 is +2 % on the 48-layer group, -4 % on single layers)
     static bool once = false;
     if (!once) {

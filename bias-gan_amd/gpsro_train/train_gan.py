@@ -212,10 +212,20 @@ class GANTrainer:
         s = self.step_count
         train_g = (s < self.warmup) or (s % self.freq_g == 0)
         train_d = (s >= self.warmup) and (s % self.freq_d == 0)
+        # everything the capture bakes into launch arguments is part of the key: a changed loss weight, criterion or
+        # optimiser hyper-parameter captures a new graph instead of silently replaying the old numbers
+        def _opt_key(o):
+            return tuple((float(g["eps"]), float(g["weight_decay"]), tuple(float(b) for b in g["betas"]),
+                          bool(g.get("amsgrad", False)), type(o).__name__ + str(g.get("decoupled", ""))) for g in o.param_groups)
         key = (tuple(inputs.shape), inputs.dtype, tuple(outputs_real.shape), masks is not None, train_g, train_d, s < self.warmup,
-               id(getattr(_unwrap(self.generator), "_bg_arena", None)), id(getattr(_unwrap(self.discriminator), "_bg_arena", None)))
+               id(getattr(_unwrap(self.generator), "_bg_arena", None)), id(getattr(_unwrap(self.discriminator), "_bg_arena", None)),
+               float(self.w_gan), float(self.w_reg), float(self.w_gp), float(self.d_loss_scale), bool(self.enable_masks),
+               id(self.criterion_regression), id(self.criterion_gan), self.loss_type_gan, id(self._gp),
+               _opt_key(self.d_opt), _opt_key(self.g_opt))
         if not hasattr(self, "_graphs"):
-            self._graphs, self._graph_seen = {}, {}
+            self._graphs, self._graph_seen, self._graph_failed = {}, {}, set()
+        if key in self._graph_failed:                            # a capture of this configuration failed once: stay eager
+            return self._eager_step(inputs, outputs_real, masks, labels, eta)
         e = self._graphs.get(key)
         if e is None and self._graph_seen.get(key, 0) < 2:       # two eager steps first: arenas, allocator, lazy state
             self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
@@ -245,12 +255,33 @@ class GANTrainer:
             if e["eta"] is not None:
                 e["eta"].copy_(eta.pin_memory() if not eta.is_cuda else eta, non_blocking=True)
         opts = ([self.d_opt] if train_d else []) + ([self.g_opt] if train_g else [])
-        for o in opts:
-            o.prepare_replay()           # step count, lr and bias corrections of THIS step -> device
         pool = _SP.get(dev)
         if "graph" not in e:
-            self._capture(e, key, opts, pool)
+            # A capture can fail where the eager step works (a host sync inside a user-supplied loss or gradient-penalty
+            # function): the optimisers' step counts are rolled back, the configuration is marked and runs eagerly for good.
+            t_before = [o._t for o in opts]
+            for o in opts:
+                o.prepare_replay()
+            try:
+                self._capture(e, key, opts, pool)
+            except Exception as err:   # noqa: BLE001 -- whatever the capture raised, the eager path is the fallback
+                for o, t in zip(opts, t_before):
+                    o._t = t
+                self._graph_failed.add(key)
+                self._graphs.pop(key, None)
+                self._d_pending, self._g_ahead, self._want_g_ahead = False, None, False
+                import warnings
+                warnings.warn(f"whole-step hipGraph capture failed ({type(err).__name__}: {err}); this configuration stays eager")
+                torch.cuda.synchronize()
+                return self._eager_step(inputs, outputs_real, masks, labels, eta)
         else:
+            for o in opts:
+                o.prepare_replay()       # step count, lr and bias corrections of THIS step -> device
+            # weights written outside the graph since the last step (load_checkpoint / load_state_dict, manual edits)
+            # bump the master arena's version: refresh the bf16 / packed copies the captured kernels read (a no-op check
+            # otherwise -- the captured Adam rewrites them itself)
+            for net in (self.generator, self.discriminator):
+                _unwrap(net).arena().sync()
             pool.used = e["pool_after"]
             for m_, k in e["nbt"]:
                 m_.__dict__["_bg_nbt_pending"] = m_.__dict__.get("_bg_nbt_pending", 0) + k
@@ -469,7 +500,7 @@ def main(pargs):
             if trainer.step_count >= pargs.max_steps:
                 break
         epoch += 1
-        if pargs.save_frequency > 0 and comm.rank() == 0:                                         # train_gan.py:419-431
+        if comm.rank() == 0:   # every epoch, whatever --save_frequency says                    # train_gan.py:419-431
             trainer.save_checkpoint(os.path.join(pargs.output_dir, pargs.model_prefix + "_epoch_" + str(epoch) + ".cpt"), epoch)
     return trainer
 

@@ -106,15 +106,27 @@ def _e32(*shape, device):
 # joined back into the caller's stream when the autograd engine finishes the pass (queue_callback),
 # so .grad is ordered like any other result of backward().  BGAMD_NO_WGRAD_STREAM=1 disables.
 _WG_STREAMS = {}
-_WG_PENDING = set()
+_WG_PENDING = {}     # device -> graph task id of the backward pass whose callback is registered
 _WG_ENABLED = not _os.environ.get("BGAMD_NO_WGRAD_STREAM")
+
+
+def _wg_register(key):
+    """One end-of-backward callback per device and backward pass.  A pass is identified by the autograd engine's graph
+    task id: if an earlier pass raised, its callback never ran -- its entry here is stale, the groups it queued are
+    dropped (their gradients belong to the failed pass) and this pass registers its own callback."""
+    task = torch._C._current_graph_task_id()   # >= 0: every caller checked that a backward pass is running
+    if _WG_PENDING.get(key, None) != task:
+        if key in _WG_PENDING:
+            _WG_GROUPS.pop(key, None)
+        _WG_PENDING[key] = task
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
 
 
 def wgrad_call(dev, tensors, name, *args):
     """Launch a weight-gradient entry point on the second stream (after everything enqueued so far on the
     caller's stream); `tensors` are the operands whose memory must outlive that launch."""
-    if not _WG_ENABLED or L.PROFILE is not None:   # the profile step times ONE kernel per event pair
-        L.call(name, *args)
+    if not _WG_ENABLED or L.PROFILE is not None or torch._C._current_graph_task_id() < 0:
+        L.call(name, *args)   # the profile step times ONE kernel per event pair; outside a backward pass nothing would join
         return
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _WG_STREAMS.get(key)
@@ -123,9 +135,7 @@ def wgrad_call(dev, tensors, name, *args):
         ent = _WG_STREAMS[key] = (side, side.cuda_stream)
     side, raw = ent
     side.wait_stream(torch.cuda.current_stream(dev))
-    if key not in _WG_PENDING:
-        _WG_PENDING.add(key)
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
+    _wg_register(key)
     for t in tensors:
         t.record_stream(side)
     L.call_on(raw, name, *args)   # the kernel only accumulates into the gradient arena: no allocation on that stream
@@ -139,7 +149,7 @@ def wgrad_join(key=None):
         ent = _WG_STREAMS.get(k)
         if ent is not None:
             torch.cuda.current_stream(ent[0].device).wait_stream(ent[0])
-        _WG_PENDING.discard(k)
+        _WG_PENDING.pop(k, None)
 
 
 # Pointwise (1x1) weight gradients are not launched layer by layer: a single 728 x 728 layer has 9 output tiles, so it can
@@ -159,9 +169,14 @@ def wgrad_group_ok(dtype, kh, kw, stride, pad, dil, has_bias) -> bool:
 def wgrad_group_add(dev, x, g, dw_ptr, rows, cin, cout, desc):
     """Queue dW += g^T x of one pointwise layer for the end-of-backward grouped launch."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _WG_PENDING:
-        _WG_PENDING.add(key)
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: wgrad_join(key))
+    if (not _gang_shape_ok(cin, cout) or torch._C._current_graph_task_id() < 0
+            or rows * max(ld_of(x), ld_of(g)) * 2 >= (1 << 31)):    # the gang kernel's 32-bit operand offsets
+        # shapes the gang kernel never takes (mostly padding in 256 x 256 tiles: the 128-channel entry-flow layers, 450 MB
+        # of gradient each at 1152 x 768, batch 8) go out now, on the side stream under the data-gradient chain, instead
+        # of holding their operands until the pass ends; so does a call from outside a backward pass (no callback to flush)
+        wgrad_call(dev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dw_ptr, None)
+        return
+    _wg_register(key)
     sig = (rows, cin, cout, ld_of(x), ld_of(g))
     _WG_GROUPS.setdefault(key, {}).setdefault(sig, []).append((x, g, dw_ptr, desc))
 
@@ -171,9 +186,13 @@ def _gang_pays(n_layers, cin, cout) -> bool:
     the 48 middle-flow layers) and for single layers with many output tiles (1536 x 1536 and up: 1.1-1.3x); a single
     layer of up to 12 tiles is 0.7-0.9x (one range per gang is too short against its flush)."""
     tiles = (-(-cin // 256)) * (-(-cout // 256))
-    if cin * cout < 0.7 * tiles * 65536:       # 256 x 256 tiles mostly padding (128-channel layers): 0.3-0.5x
-        return False
-    return n_layers >= 2 or tiles >= 24
+    return _gang_shape_ok(cin, cout) and (n_layers >= 2 or tiles >= 24)
+
+
+def _gang_shape_ok(cin, cout) -> bool:
+    """256 x 256 tiles mostly padding (128-channel layers): 0.3-0.5x of the per-layer kernel, whatever the group size."""
+    tiles = (-(-cin // 256)) * (-(-cout // 256))
+    return cin * cout >= 0.7 * tiles * 65536
 
 
 def wgrad_group_flush(key):

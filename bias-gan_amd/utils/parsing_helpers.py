@@ -248,7 +248,11 @@ def resume_lr_schedule(start_lr, scheduler_arg, optimizer, start_step):
     constructor then performs one step of its own, so the reference's resumed run is one scheduler step AHEAD of the
     run that wrote the checkpoint (a milestone at start_step + 1 fires before the first resumed update).  Here the
     schedule is built from step 0 and moved to `start_step` with its closed form: same LR at every step as an
-    uninterrupted run."""
+    uninterrupted run WHEN each scheduler stepped once per loop iteration of the saved run (--update_frequency_* 1 and
+    no generator warm-up: the launcher's values).  With other update frequencies a scheduler steps only on its own
+    network's updates, so `start_step` overcounts its position; the checkpoint carries no scheduler counters (the
+    reference's does not either), and the resumed LR is then that of loop step `start_step`.  INTEGRATION.md records
+    this deviation from the reference."""
     for g in optimizer.param_groups:
         g["lr"] = g.get("initial_lr", start_lr)
     sched = get_lr_schedule(start_lr, scheduler_arg, optimizer, last_step=-1)

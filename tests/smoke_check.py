@@ -1,6 +1,6 @@
 """One small G+D training iteration on the GPU, checked against the CPU oracle.
-Called by __graft_entry__.smoke().  (The oracle import lives here on purpose:
-this module is the smoke check, not the product path.)"""
+Called by __graft_entry__.smoke().  Lives under tests/ (not in the package): it imports
+the oracle, which only tests, smoke() and bench.py's cpu_baseline leg may do."""
 import os
 import sys
 
@@ -12,11 +12,12 @@ def run(device="cuda:0", c=4, h=64, w=64, n=2):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
+    import bias_gan_amd  # noqa: F401  (the import shim of the hyphenated package directory)
     from oracle import gan_oracle as orc
-    from .architecture.gpsro import deeplab_gan as dxg
-    from .gpsro_train.train_gan import GANTrainer
-    from .utils import losses
-    from .utils import parsing_helpers as ph
+    from bias_gan_amd.architecture.gpsro import deeplab_gan as dxg
+    from bias_gan_amd.gpsro_train.train_gan import GANTrainer
+    from bias_gan_amd.utils import losses
+    from bias_gan_amd.utils import parsing_helpers as ph
 
     results = {}
     # fp32 path: the oracle's own tolerance.  bf16 path: storage rounding through the randomly filled 140-layer

@@ -3,6 +3,9 @@ draws, optimiser/schedule plumbing, and the N>1 path (world_size 2 over gloo).""
 import json
 import os
 import socket
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import numpy as np
 import pytest
@@ -195,3 +198,19 @@ def test_resume_lr_schedule_continues_exactly():
                 assert abs(o2.param_groups[0]["lr"] - lrs[k]) < 1e-12, (arg["type"], start, k)
                 o2.step()
                 s2.step()
+
+
+def test_bench_plain_multi_gpu_launch_starts_one_process_per_gpu():
+    """`python bench.py --gpus N` without a launcher environment must not exit: the parent (which never touches the GPU)
+    starts torch.distributed.run with N ranks on 127.0.0.1 and relays their output."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BGAMD_BENCH_LAUNCH_ECHO"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
