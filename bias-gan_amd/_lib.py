@@ -12,7 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BGAMD_LIB") or os.path.join(_HERE, "libbgamd.so")   # BGAMD_LIB: experiment builds
 
-BF16, F32 = 0, 1
+BF16, F32, FP8 = 0, 1, 2
+FP8_E4M3, FP8_E5M2 = 0, 1
 ABI_VERSION = 1
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -56,6 +57,11 @@ _SIGS = {
     "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight_grouped": [c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_pack_conv_weights": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
+    "bg_quant_fp8": [c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "bg_fp8_roll": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
+    "bg_pack_conv_weights_fp8": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp],
+    "bg_conv2d_fwd_fp8": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "bg_conv2d_bwd_data_fp8": [C.POINTER(ConvDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_fwd": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_data": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_weight": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
@@ -216,6 +222,14 @@ def _alg_bytes(name, a) -> float:
     nn = lambda *idx: sum(1 for i in idx if a[i] is not None)  # noqa: E731
     if name == "bg_conv2d_bwd_weight_grouped":
         return float(a[2]) * (float(a[3]) * (a[4] + a[5]) * 2 + 4.0 * a[4] * a[5])
+    if name == "bg_conv2d_fwd_fp8":       # fp8 bytes in, fp8 weights, bf16 out
+        d = a[0]
+        return float(d.N) * (d.H * d.W * d.Cin + 2 * d.Ho * d.Wo * d.Cout) + d.Cout * d.Cin * d.KH * d.KW
+    if name == "bg_conv2d_bwd_data_fp8":  # fp8 dy in, fp8 weights, bf16 dx out
+        d = a[0]
+        return float(d.N) * (2 * d.H * d.W * d.Cin + d.Ho * d.Wo * d.Cout) + d.Cout * d.Cin * d.KH * d.KW
+    if name == "bg_quant_fp8":            # source once, fp8 copy once
+        return float(a[3]) * (a[4] * _es(a[0]) + a[7])
     if name.startswith("bg_conv2d"):     # every operand once: activation in, activation out, weights
         d = a[0]
         es = _es(d.dtype)

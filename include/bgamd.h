@@ -47,6 +47,9 @@ extern "C" {
 
 #define BG_BF16 0
 #define BG_F32 1
+#define BG_FP8 2 /* operand storage of the bg_*_fp8 entry points only (OCP e4m3 / e5m2, one byte per element) */
+#define BG_FP8_E4M3 0
+#define BG_FP8_E5M2 1
 
 #define BG_OK 0
 #define BG_E_ARG (-1)    /* bad argument / shape the kernels do not support */
@@ -117,6 +120,37 @@ int bg_conv_set_variant(int32_t variant);
  * flat buffers; max_elems = largest K*RS*Cp + C*RS*Kp over the layers. */
 int bg_pack_conv_weights(int32_t dtype, const void* src, void* dst_krsc, void* dst_crsk, const int64_t* tbl,
                          int32_t n_layers, int64_t max_elems, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * fp8 operand path of the dense convolutions (BASELINE.json configs[4]: "fp8 MFMA conv path with bf16
+ * accumulate"; no counterpart in the reference -- it replaces the same nn.Conv2d calls as bg_conv2d_fwd /
+ * _bwd_data).  Operands are OCP fp8 bytes, q = round_to_nearest_even(clamp(v * 2^e, +-max)) with ONE power-of-two
+ * exponent e per tensor kept in device memory; the MFMA is the block-scaled 16x16x128 f8f6f4 form (twice the bf16
+ * rate, fp32 accumulation) whose hardware block scales carry 2^-e, so outputs are in real units.  Outputs, the
+ * statistics epilogue, tiling and determinism are those of the bf16 fat-tile kernel (bf16 y / dx, fp64 sums).
+ *
+ * bg_quant_fp8: xq[r][c] = fp8(x[r][c] * 2^(*exp)) for c < C, zeros for C <= c < Cq (Cq = C rounded up to 16: the
+ *   16-byte vector of one-byte elements); src_dtype BG_BF16 | BG_F32; fmt BG_FP8_E4M3 (max 448) | BG_FP8_E5M2
+ *   (max 57344).  amax (may be NULL): *amax = max(*amax, max |x|) as the bits of a non-negative float (atomic max on
+ *   uint32) -- the statistic bg_fp8_roll turns into the NEXT call's exponent (delayed scaling).
+ * bg_fp8_roll: for i < n: exp[i] = floor(log2(max_of(fmt[i]) / amax[i])) - margin (0 where amax[i] == 0), amax[i] = 0.
+ * bg_pack_conv_weights_fp8: bg_pack_conv_weights from the fp32 master layout into e4m3 KRSC / CRSK copies (reduction
+ *   dimension zero-padded to 128), one exponent per layer derived from the layer's own max |w| in the same call
+ *   (exps[n_layers], amax_ws[n_layers] scratch; tbl as bg_pack_conv_weights with Cp / Kp multiples of 128).
+ * bg_conv2d_fwd_fp8: y (bf16) = conv(xq, wq) (+ bias); sum/sumsq as bg_conv2d_fwd_stats (NULL: none).  d->dtype must
+ *   be BG_BF16 (the output type); d->Cin / d->ldx describe xq (bytes; multiples of 16).
+ * bg_conv2d_bwd_data_fp8: dx (bf16) = conv_transpose(dyq, wtq); dy_fmt names dyq's format; d->Cout / d->ldy
+ *   describe dyq, d->Cin / d->ldx the bf16 dx.
+ * ------------------------------------------------------------------------- */
+int bg_quant_fp8(int32_t src_dtype, const void* x, int32_t ldx, int64_t rows, int32_t C, void* xq, int32_t ldq, int32_t Cq,
+                 int32_t fmt, const int32_t* exp, uint32_t* amax, void* stream);
+int bg_fp8_roll(int32_t* exp, uint32_t* amax, const int32_t* fmt, int32_t n, int32_t margin, void* stream);
+int bg_pack_conv_weights_fp8(const float* src, void* dst_krsc, void* dst_crsk, const int64_t* tbl, int32_t n_layers,
+                             int64_t max_elems, int32_t* exps, uint32_t* amax_ws, void* stream);
+int bg_conv2d_fwd_fp8(const bg_conv_desc* d, const void* xq, const void* wq, const int32_t* exp_x, const int32_t* exp_w,
+                      const float* bias, void* y, double* sum, double* sumsq, int32_t groups, void* stream);
+int bg_conv2d_bwd_data_fp8(const bg_conv_desc* d, const void* dyq, int32_t dy_fmt, const void* wtq, const int32_t* exp_dy,
+                           const int32_t* exp_w, void* dx, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Depthwise 3x3 of SeparableConv2d_same, with fixed_padding folded in
