@@ -332,9 +332,50 @@ class GANTrainer:
         if train_generator:
             g_loss = self.g_step(inputs, outputs_real, masks)
         self._finish_d()
+        for net in (self.generator, self.discriminator):   # fp8 operand path: next step's exponents from this step's maxima
+            a = getattr(_unwrap(net), "_bg_arena", None)
+            if a is not None and a.fp8:
+                a.roll_fp8()
         self.step_count += 1
         return d_loss, g_loss
 
+
+    # -- fp8 operand path: calibration ------------------------------------------------------------------
+    def calibrate_fp8(self, inputs, outputs_real, masks=None):
+        """Give every fp8 quantisation site its first exponent without changing the training state.
+
+        The fp8 path scales each quantised tensor by a power of two taken from the max |value| the site saw ONE STEP
+        EARLIER (delayed scaling); before a site has seen anything its GEMM runs on the bf16 operands.  This runs one
+        loop iteration on (inputs, outputs_real) -- every site records its maximum -- and then puts parameters,
+        BatchNorm buffers, optimiser moments, schedules, the step count and the host RNG back, so that the NEXT call of
+        step() is the run's first iteration, on fp8 operands.  Without it the first iteration is the calibration (bf16
+        GEMMs).  No-op for networks that are not in fp8 mode."""
+        import copy
+        nets = [_unwrap(self.generator), _unwrap(self.discriminator)]
+        if not any(getattr(n, "_bg_fp8", False) for n in nets):
+            return
+        snap_net = [{k: v.detach().clone() for k, v in n.state_dict().items()} for n in nets]
+        opts = [self.g_opt, self.d_opt]
+        snap_opt = [copy.deepcopy(o.state_dict()) for o in opts]
+        scheds = [self.g_scheduler, self.d_scheduler]
+        snap_sched = [None if sc is None else copy.deepcopy(sc.state_dict()) for sc in scheds]
+        rng, step = torch.get_rng_state(), self.step_count
+        try:
+            self._eager_step(inputs, outputs_real, masks)
+        finally:
+            for n, sd in zip(nets, snap_net):
+                n.load_state_dict(sd)
+                for m in n.modules():
+                    if m.__dict__.get("_bg_nbt_pending", 0):
+                        m.__dict__["_bg_nbt_pending"] = 0
+            for o, sd in zip(opts, snap_opt):
+                o.load_state_dict(sd)
+            for sc, sd in zip(scheds, snap_sched):
+                if sc is not None:
+                    sc.load_state_dict(sd)
+            torch.set_rng_state(rng)
+            self.step_count = step
+            self._d_pending, self._g_ahead = False, None
 
     # -- train_gan.py:330-398 -----------------------------------------------------------
     @torch.no_grad()

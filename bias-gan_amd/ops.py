@@ -341,6 +341,32 @@ def _splitk_finish(ws, y):
     L.call("bg_splitk_reduce", L.dt(y.dtype), ws.data_ptr(), splits, rows, c, y.data_ptr(), ld_of(y))
 
 
+# ---- fp8 operand path (BASELINE.json configs[4]; include/bgamd.h "fp8 operand path") --------------------------------
+def fp8_layer_ok(arena: Arena, wslot: ParamSlot, kh, kw) -> bool:
+    """Which dense convolutions take fp8 operands: reductions of at least 256 (below that the launch is an HBM-bound copy
+    whatever the operand type) onto at least 64 output channels."""
+    if not getattr(arena, "fp8", False) or wslot.f8 is None:
+        return False
+    kp, _, _, cp = wslot.phys_shape
+    return cp * kh * kw >= 256 and kp >= 64 and cp >= 64
+
+
+def fp8_quant(t: torch.Tensor, fmt: int, exp_ptr: int, amax_ptr: int) -> torch.Tensor:
+    """fp8 copy of an NHWC bf16 tensor: [N, H, W, Cq] bytes, Cq = C rounded up to 16 (zero lanes), pixel stride rounded
+    up to 64 bytes; quantised with the site's exponent, the site's running max |value| updated."""
+    n, h, w, c = t.shape
+    cq = (c + 15) // 16 * 16
+    ldq = (cq + 63) // 64 * 64
+    q = torch.empty((n, h, w, ldq), dtype=torch.uint8, device=t.device)
+    L.call("bg_quant_fp8", L.dt(t.dtype), t.data_ptr(), ld_of(t), n * h * w, c, q.data_ptr(), ldq, cq, fmt, exp_ptr, amax_ptr)
+    return q[..., :cq]
+
+
+def fp8_amax_only(t: torch.Tensor, fmt: int, exp_ptr: int, amax_ptr: int):
+    """Calibration step: only the site's max |value| is wanted (the GEMM runs on the bf16 operand)."""
+    fp8_quant(t, fmt, exp_ptr, amax_ptr)
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d(groups=1) as implicit GEMM (bg_conv2d_*)."""
 
@@ -358,7 +384,26 @@ class Conv2dFn(torch.autograd.Function):
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
         splits = splitk_plan(n * ho * wo, kp, cin, kh, kw, x.dtype) if bslot is None else 0
-        if splits:
+        use8 = x.dtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw)
+        if use8:
+            # fp8 operands: the input's e4m3 copy (the producer's, if it made one; else one quantisation pass) against the
+            # arena's e4m3 weights; bf16 output and statistics as below.  Until the sites have been calibrated (the first
+            # training step) the GEMM stays on bf16 and the quantiser only records the input's max |value|.
+            ep, ap = arena.site_ptrs(wslot, grad=False)
+            xq = getattr(x, "_bg_fp8", None)
+            if xq is None or xq[1] != ep or not arena.sites_ready:
+                xq = (fp8_quant(x, L.FP8_E4M3, ep, ap), ep)
+            use8 = arena.sites_ready
+        if use8:
+            xq = xq[0]
+            d8 = L.ConvDesc(L.BF16, n, h, w, xq.shape[3], ho, wo, kp, kh, kw, stride, pad, dil, ld_of(xq), ld_of(y))
+            if stats is not None:
+                assert bslot is None and stats.dim() == 3 and stats.shape[0] == 2 and stats.shape[2] == kp
+            L.call("bg_conv2d_fwd_fp8", d8, xq.data_ptr(), arena.weight8_ptr(wslot), ep, arena.w_exp_ptr(wslot),
+                   None if bslot is None else arena.master_ptr(bslot), y.data_ptr(),
+                   None if stats is None else stats[0].data_ptr(), None if stats is None else stats[1].data_ptr(),
+                   1 if stats is None else stats.shape[1])
+        elif splits:
             ws = torch.empty((splits, n * ho * wo, kp), dtype=torch.float32, device=x.device)
             L.call("bg_conv2d_fwd_splitk", desc, x.data_ptr(), arena.weight_ptr(wslot), ws.data_ptr(), splits)
             _splitk_finish(ws, y)
@@ -392,7 +437,19 @@ class Conv2dFn(torch.autograd.Function):
             dx = new_act(n, h, w, cin, xdtype, xdev)
             d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(dx), ld_of(g))
             splits = splitk_plan(n * h * w, cin, kp, kh, kw, xdtype)
-            if splits:
+            use8 = xdtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw) and cin >= 64
+            if use8:
+                ep, ap = arena.site_ptrs(wslot, grad=True)
+                gq = getattr(g, "_bg_fp8", None)
+                if gq is None or gq[1] != ep or not arena.sites_ready:
+                    gq = (fp8_quant(g, L.FP8_E5M2, ep, ap), ep)
+                use8 = arena.sites_ready
+            if use8:
+                gq = gq[0]
+                d8 = L.ConvDesc(L.BF16, n, h, w, cin, ho, wo, gq.shape[3], kh, kw, stride, pad, dil, ld_of(dx), ld_of(gq))
+                L.call("bg_conv2d_bwd_data_fp8", d8, gq.data_ptr(), L.FP8_E5M2, arena.weight8_t_ptr(wslot), ep,
+                       arena.w_exp_ptr(wslot), dx.data_ptr())
+            elif splits:
                 ws = torch.empty((splits, n * h * w, cin), dtype=torch.float32, device=xdev)
                 L.call("bg_conv2d_bwd_data_splitk", d2, g.data_ptr(), arena.weight_t_ptr(wslot), ws.data_ptr(), splits)
                 _splitk_finish(ws, dx)

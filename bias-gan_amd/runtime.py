@@ -37,7 +37,7 @@ def pad_to(c: int, v: int) -> int:
 
 class ParamSlot:
     """Where one nn.Parameter lives inside the arenas."""
-    __slots__ = ("name", "param", "kind", "off", "numel", "phys_shape", "t_off", "k_off", "krsc")
+    __slots__ = ("name", "param", "kind", "off", "numel", "phys_shape", "t_off", "k_off", "krsc", "f8", "k8_off", "t8_off")
 
     def __init__(self, name, param, kind, phys_shape):
         self.name, self.param, self.kind, self.phys_shape = name, param, kind, tuple(phys_shape)
@@ -48,6 +48,8 @@ class ParamSlot:
         self.t_off = -1   # offset inside the packed CRSK arena, dense convs only
         self.k_off = -1   # offset inside the packed KRSC arena, dense convs only
         self.krsc = None  # (K, RS, C, Cp, Kp) for dense convs
+        self.f8 = None    # index into the arena's fp8 tables (dense convs of an fp8 arena)
+        self.k8_off = self.t8_off = -1
 
 
 class StatsPool:
@@ -104,8 +106,9 @@ def arena_of(p):
 class Arena:
     """Flat storage for the parameters of one network (see module docstring)."""
 
-    def __init__(self, root: nn.Module, compute_dtype: torch.dtype):
+    def __init__(self, root: nn.Module, compute_dtype: torch.dtype, fp8: bool = False):
         self.compute_dtype = compute_dtype
+        self.fp8 = bool(fp8) and compute_dtype == torch.bfloat16
         self.slots: List[ParamSlot] = []
         self.by_param: Dict[int, ParamSlot] = {}
         dev = None
@@ -163,9 +166,64 @@ class Arena:
         self._synced_version = -1
         self.ddp = None
         self.attach_grads()
+        if self.fp8:
+            self._build_fp8()
         import weakref
         for s in self.slots:
             _ARENA_OF[id(s.param)] = weakref.ref(self)
+
+    # -- fp8 operand path (BASELINE.json configs[4]) ---------------------------------------
+    def _build_fp8(self):
+        """e4m3 copies of the dense conv weights (reduction dim zero-padded to 128) with one power-of-two exponent per
+        layer, and the quantisation sites of the activations: two per layer (forward input: e4m3; output gradient:
+        e5m2) with delayed scaling -- a site's exponent comes from the max |value| it saw in the previous step
+        (bg_quant_fp8 records it, roll_fp8() turns it into the next step's exponent)."""
+        dev = self.device
+        layers = [s for s in self.slots if s.krsc is not None]
+        k_off = t_off = 0
+        rows = []
+        for i, s in enumerate(layers):
+            k, rs, c, _, _ = s.krsc
+            c8, k8 = pad_to(pad_to(c, 16), 128), pad_to(pad_to(k, 16), 128)
+            s.f8 = i
+            s.k8_off, s.t8_off = k_off, t_off
+            rows.append([s.off, k_off, t_off, k, rs, c, c8, k8])
+            k_off += pad_to(k * rs * c8, 64)
+            t_off += pad_to(c * rs * k8, 64)
+        n = max(len(layers), 1)
+        self.wk8 = torch.zeros(max(k_off, 16), dtype=torch.uint8, device=dev)
+        self.wt8 = torch.zeros(max(t_off, 16), dtype=torch.uint8, device=dev)
+        self.tbl8 = torch.tensor(rows if rows else [[0] * 8], dtype=torch.int64, device=dev)
+        self.max8 = max([r[3] * r[4] * r[6] + r[5] * r[4] * r[7] for r in rows] + [1])
+        self.w_exp = torch.zeros(n, dtype=torch.int32, device=dev)
+        self._w_amax = torch.zeros(n, dtype=torch.int32, device=dev)
+        # sites: 2 * layer + 0 = forward input (e4m3), 2 * layer + 1 = output gradient (e5m2)
+        self.site_exp = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+        self.site_amax = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+        self.site_fmt = torch.tensor([L.FP8_E4M3, L.FP8_E5M2] * n, dtype=torch.int32, device=dev)
+        self.sites_ready = False       # the first step calibrates: bf16 GEMMs, the quantiser only records max |value|
+        self.n_fp8_layers = len(layers)
+
+    def roll_fp8(self):
+        """End of a training step: exponents of the next step from this step's recorded maxima (one bit of head-room)."""
+        if self.fp8 and self.n_fp8_layers:
+            L.call("bg_fp8_roll", self.site_exp.data_ptr(), self.site_amax.data_ptr(), self.site_fmt.data_ptr(),
+                   2 * self.n_fp8_layers, 1)
+            self.sites_ready = True
+
+    def weight8_ptr(self, s: ParamSlot) -> int:
+        return self.wk8.data_ptr() + s.k8_off
+
+    def weight8_t_ptr(self, s: ParamSlot) -> int:
+        return self.wt8.data_ptr() + s.t8_off
+
+    def w_exp_ptr(self, s: ParamSlot) -> int:
+        return self.w_exp.data_ptr() + 4 * s.f8
+
+    def site_ptrs(self, s: ParamSlot, grad: bool):
+        """(exponent pointer, amax pointer) of a layer's forward-input / output-gradient site."""
+        i = 2 * s.f8 + (1 if grad else 0)
+        return self.site_exp.data_ptr() + 4 * i, self.site_amax.data_ptr() + 4 * i
 
     # -- views ---------------------------------------------------------------------
     def _view(self, flat: torch.Tensor, s: ParamSlot) -> torch.Tensor:
@@ -228,6 +286,9 @@ class Arena:
             src = self.lp if self.lp is not None else self.master
             L.call("bg_pack_conv_weights", L.dt(self.compute_dtype), src.data_ptr(), self.wk.data_ptr(),
                    self.wt.data_ptr(), self.tr_tbl.data_ptr(), self.tr_layers, self.tr_max)
+            if self.fp8:   # from the fp32 master: one rounding, per-layer exponent from the layer's own max |w|
+                L.call("bg_pack_conv_weights_fp8", self.master.data_ptr(), self.wk8.data_ptr(), self.wt8.data_ptr(),
+                       self.tbl8.data_ptr(), self.n_fp8_layers, self.max8, self.w_exp.data_ptr(), self._w_amax.data_ptr())
 
     def weight_ptr(self, s: ParamSlot) -> int:
         """Device pointer of the compute-dtype operand copy of a parameter: packed KRSC for
@@ -254,6 +315,7 @@ class BGModule(nn.Module):
 
     _bg_arena: Optional[Arena] = None
     _bg_dtype: Optional[torch.dtype] = None
+    _bg_fp8: bool = False
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -276,9 +338,16 @@ class BGModule(nn.Module):
         return self._bg_dtype or default_compute_dtype()
 
     def set_compute_dtype(self, dtype: torch.dtype):
+        """torch.float32: the parity path; torch.bfloat16: the measured path; torch.float8_e4m3fn: bf16 storage with the
+        dense convolutions' forward and data-gradient GEMMs on fp8 operands (e4m3 weights and inputs, e5m2 output
+        gradients, fp32 accumulation: BASELINE.json configs[4])."""
+        fp8 = dtype == torch.float8_e4m3fn
+        if fp8:
+            dtype = torch.bfloat16
         for m in self.modules():
             if isinstance(m, BGModule):
                 object.__setattr__(m, "_bg_dtype", dtype)
+                object.__setattr__(m, "_bg_fp8", fp8)
                 object.__setattr__(m, "_bg_arena", None)
         return self
 
@@ -291,7 +360,7 @@ class BGModule(nn.Module):
             if first is None or first.device.type != "cuda":
                 raise RuntimeError("bias_gan_amd: the HIP path needs the module on a GPU (call .to('cuda')); "
                                    "there is no CPU fallback")
-            a = Arena(self, self.compute_dtype())
+            a = Arena(self, self.compute_dtype(), self._bg_fp8)
             for m in self.modules():
                 if isinstance(m, BGModule):
                     object.__setattr__(m, "_bg_arena", a)

@@ -235,3 +235,174 @@ def test_fp8_mfma_operand_map_with_exact_integers():
     torch.cuda.synchronize()
     ref = (x @ wt.view(cout, cin).t()).to(torch.bfloat16).float()      # integers < 2^8 in magnitude survive bf16 or round alike
     assert torch.equal(y.float().cpu().view(-1, cout), ref)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# model level: compute_dtype = torch.float8_e4m3fn (bf16 storage, fp8 GEMM operands with delayed scaling)
+import numpy as np  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from bias_gan_amd import ops  # noqa: E402
+from bias_gan_amd.architecture.gpsro import deeplab_gan as dxg  # noqa: E402
+from bias_gan_amd.gpsro_train.train_gan import GANTrainer  # noqa: E402
+from bias_gan_amd.runtime import pad_to, vec_of  # noqa: E402
+from bias_gan_amd.utils import losses  # noqa: E402
+from bias_gan_amd.utils import parsing_helpers as ph  # noqa: E402
+from oracle import gan_oracle as orc  # noqa: E402
+
+FP8 = torch.float8_e4m3fn
+
+
+def rms_err(got, ref):
+    got, ref = torch.as_tensor(got).double(), torch.as_tensor(ref).double()
+    return ((got - ref).pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+def build(c, h, w, dtype, seeds=(21, 22)):
+    gspec, dspec = orc.generator_spec(c, c, 0, "batch"), orc.discriminator_spec(c, h, w, "batch")
+    G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d, compute_dtype=dtype)
+    D = dxg.Discriminator(c, normalizer=nn.BatchNorm2d, input_size=(h, w), compute_dtype=dtype)
+    G.load_state_dict(orc.fill_state(gspec, seeds[0])), D.load_state_dict(orc.fill_state(dspec, seeds[1]))
+    return G.to(DEV).train(), D.to(DEV).train(), gspec, dspec
+
+
+def trainer(G, D, n, mode="ModifiedMinMax"):
+    crit = losses.GANLoss(mode, n, torch.device(DEV))
+    return GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5),
+                      ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5), crit, losses.L1Loss(), loss_type_gan=mode,
+                      loss_weight_gp=10.0), crit
+
+
+def test_fp8_mode_uses_the_fp8_kernels_after_calibration(monkeypatch):
+    """The first step of an fp8-mode trainer is the calibration (bf16 GEMMs, every site records its maximum): same
+    launches as the bf16 path plus the quantiser.  From the second step on the eligible convolutions launch
+    bg_conv2d_fwd_fp8 / bg_conv2d_bwd_data_fp8.  Counted through the library's launch profile hook."""
+    monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    c, h, w, n = 4, 64, 64, 2
+    G, D, _, _ = build(c, h, w, FP8)
+    tr, _ = trainer(G, D, n)
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 1000))
+    counts = []
+    for _ in range(2):
+        L.PROFILE = []
+        tr.step(x, y)
+        torch.cuda.synchronize()
+        names = [p[0] for p in L.PROFILE]
+        L.PROFILE = None
+        counts.append({k: names.count(k) for k in ("bg_conv2d_fwd_fp8", "bg_conv2d_bwd_data_fp8", "bg_quant_fp8", "bg_conv2d_fwd_stats",
+                                                    "bg_conv2d_bwd_data", "bg_fp8_roll")})
+    print(counts)
+    assert counts[0]["bg_conv2d_fwd_fp8"] == 0 and counts[0]["bg_conv2d_bwd_data_fp8"] == 0 and counts[0]["bg_quant_fp8"] > 100
+    assert counts[1]["bg_conv2d_fwd_fp8"] > 100 and counts[1]["bg_conv2d_bwd_data_fp8"] > 100
+    assert counts[1]["bg_conv2d_fwd_stats"] < counts[0]["bg_conv2d_fwd_stats"] // 4
+    assert counts[0]["bg_fp8_roll"] == 2 and counts[1]["bg_fp8_roll"] == 2
+    a = G.arena()
+    ex = a.site_exp.cpu()
+    assert a.sites_ready and (ex[1::2] > 4).sum() > 50, "gradient sites should have picked large exponents"
+
+
+def test_calibrate_fp8_leaves_the_training_state_untouched():
+    c, h, w, n = 4, 64, 64, 2
+    G, D, _, _ = build(c, h, w, FP8)
+    tr, _ = trainer(G, D, n)
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 1000))
+    G(x), D(y)                                   # arenas exist
+    before = {k: v.clone() for net in (G, D) for k, v in net.state_dict().items()}
+    torch.manual_seed(5)
+    r0 = torch.get_rng_state()
+    tr.calibrate_fp8(x, y)
+    assert torch.equal(torch.get_rng_state(), r0) and tr.step_count == 0 and tr.g_opt._t == 0 and tr.d_opt._t == 0
+    after = {k: v for net in (G, D) for k, v in net.state_dict().items()}
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    assert G.arena().sites_ready and D.arena().sites_ready and int((G.arena().site_exp != 0).sum()) > 50
+
+
+def test_blocks_teacher_forced_fp8():
+    """Per-Block error of the fp8 operand path without the cascade (the bf16 version is test_parity_gpu.py's
+    test_blocks_teacher_forced_bf16): each Xception block of the generator gets the fp32 oracle's input and its output
+    is compared with the oracle's.  e4m3 carries 3 mantissa bits (relative step 2^-4 .. 2^-3, rms ~ 2.5 % per operand);
+    a block chains 3-4 pointwise GEMMs on such operands.  Bounds = 2 x the largest value measured (printed with -s)."""
+    c, h, w, n = 16, 64, 96, 2
+    spec = orc.generator_spec(c, c, 0, "batch")
+    G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d, compute_dtype=FP8)
+    G.load_state_dict(orc.fill_state(spec, 7))
+    G.to(DEV).train()
+    P = orc.fill_state(spec, 7)
+    x, y0 = orc.synthetic_fields(n, c, h, w, 3)
+    losses.L1Loss()(G(x.to(DEV)), y0.to(DEV)).backward()       # calibration pass: every site sees its tensors
+    G.arena().roll_fp8()
+    ctx = orc.NormCtx("batch", True, update_stats=False)
+    pre = "model.xception_features."
+    xf = G.model.xception_features
+    worst = 0.0
+    BF16 = torch.bfloat16
+    with torch.no_grad():
+        t = orc.lrelu(orc.norm(P, pre + "bn1", F.conv2d(x, P[pre + "conv1.weight"], None, 2, 1), ctx))
+        t = orc.lrelu(orc.norm(P, pre + "bn2", F.conv2d(t, P[pre + "conv2.weight"], None, 1, 1), ctx))
+        for cfg in orc.xception_block_table(16):
+            yb = orc.block(P, pre + cfg["name"] + ".", cfg, t, ctx)
+            xi = ops.ToInternal.apply(t.to(DEV), pad_to(t.shape[1], vec_of(BF16)), BF16)
+            got = ops.FromInternal.apply(getattr(xf, cfg["name"])(xi), cfg["cout"]).float().cpu()
+            e = rms_err(got, yb)
+            print(f"{cfg['name']:8s} {tuple(yb.shape)} fp8 rms-rel {e:.2e}")
+            worst = max(worst, e)
+            t = yb
+    print(f"worst over blocks: rms-rel {worst:.2e}")
+    assert worst <= 1.31e-1, worst      # measured 6.54e-2 (block20; the middle flow 2.1e-2 .. 6.2e-2)
+
+
+@pytest.mark.parametrize("mode", ["ModifiedMinMax", "Wasserstein"])
+def test_fp8_first_iteration_vs_oracle(mode, monkeypatch):
+    """One whole loop iteration (both Adam updates) of the fp8 path after calibrate_fp8 against oracle.GANStep (fp32, CPU)
+    on the same seeded inputs and labels, next to the bf16 path's distance from the same oracle.  The randomly filled
+    140-layer nets amplify storage rounding (bf16 end-to-end: ~1e-1); fp8 operands add to it."""
+    monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    c, h, w, n = 4, 64, 64, 2
+    x, y = orc.synthetic_fields(n, c, h, w, 1000)
+    res = {}
+    for dtype in (torch.bfloat16, FP8):
+        G, D, gspec, dspec = build(c, h, w, dtype)
+        tr, crit = trainer(G, D, n, mode)
+        tr.calibrate_fp8(x.to(DEV), y.to(DEV))
+        torch.manual_seed(333)
+        labels = crit.draw_labels() if mode == "ModifiedMinMax" else None
+        eta = torch.rand(n, 1, 1, 1) if mode == "Wasserstein" else None
+        d_loss, g_loss = tr.step(x.to(DEV), y.to(DEV), labels=labels, eta=eta)
+        res[dtype] = (float(d_loss), float(g_loss))
+    st = orc.GANStep(orc.fill_state(gspec, 21), orc.fill_state(dspec, 22), orc.trainable_keys(gspec), orc.trainable_keys(dspec),
+                     "batch", mode, w_gp=10.0)
+    d_ref, g_ref = st.step(x, y, labels=labels, eta=eta)
+    for dtype, (d, g) in res.items():
+        print(f"{mode} {dtype}: d_loss {d:.5f} (oracle {d_ref:.5f}, rel {abs(d - d_ref) / abs(d_ref):.2e})  g_loss {g:.5f} "
+              f"(oracle {g_ref:.5f}, rel {abs(g - g_ref) / abs(g_ref):.2e})")
+    d, g = res[FP8]
+    assert np.isfinite(d) and np.isfinite(g)
+    # measured: d_loss 5.7e-2 / 3.9e-2, g_loss 7.1e-2 / 7.8e-2 (bf16 path on the same inputs: 3.0e-2 / 2.6e-2, 1.7e-2 / 1.4e-2)
+    assert abs(d - d_ref) <= 1.2e-1 * abs(d_ref) and abs(g - g_ref) <= 1.6e-1 * abs(g_ref)
+
+
+def test_fp8_whole_step_graph(monkeypatch):
+    """The captured step (third call onwards) with fp8 operands: quantisers, fp8 GEMMs and the exponent roll are graph
+    nodes, the exponents live in device memory.  With the learning rate at 0 a replayed step must equal the eager one."""
+    c, h, w, n = 4, 64, 64, 2
+
+    def run(flag):
+        monkeypatch.setenv("BGAMD_STEP_GRAPH", flag)
+        G, D, _, _ = build(c, h, w, FP8, seeds=(41, 42))
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        tr = GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 0.0, 1e-8, 0.0), ph.get_optimizer(D.parameters(), "Adam", 0.0, 1e-8, 0.0),
+                        crit, losses.L1Loss())
+        out = []
+        for s_ in range(5):
+            torch.manual_seed(300 + s_)
+            x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 700 + s_))
+            d_loss, g_loss = tr.step(x, y)
+            out.append((float(d_loss), float(g_loss)))
+        return out, len(getattr(tr, "_graphs", {})), G.arena().site_exp.cpu()
+
+    (e, ge, xe), (g, gg, xg) = run("0"), run("1")
+    assert ge == 0 and gg == 1
+    assert torch.equal(xe, xg), "the exponent history of the replayed run differs from the eager one"
+    for i, (a, b) in enumerate(zip(e, g)):
+        print(f"step {i}: eager d {a[0]:.6f} g {a[1]:.6f} | graph d {b[0]:.6f} g {b[1]:.6f}")
+        assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]), (i, a, b)
