@@ -49,6 +49,8 @@ def w_alg_tflop(h, w, c, loss):
     g, d = FWD_GMAC[(h, w, c)]
     return 2.0 * (4 * g + (10 if loss == "wgan-gp" else 8) * d) * 1e-3
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (the block-scaled f8f6f4 MFMA forms; same table)
+PEAK_F32_TFLOPS = 157.3
 
 
 def parse():
@@ -60,7 +62,10 @@ def parse():
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--channels", type=int, default=16)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="bf16: the headline; f32: the parity path; fp8: bf16 storage with the dense convolutions' forward and "
+                         "data-gradient GEMMs on fp8 operands (block-scaled MFMA 16x16x128, fp32 accumulation) -- BASELINE.json "
+                         "configs[4] at --height 2304 --width 1536 --channels 32")
     ap.add_argument("--loss", default="mmm", choices=["mmm", "wgan-gp"],
                     help="mmm: ModifiedMinMax + L1 (configs[2], the headline); wgan-gp: Wasserstein + gradient penalty "
                          "(configs[3]: one more D forward and a data-gradient-only D backward per step)")
@@ -262,7 +267,7 @@ def main():
     seed = 333 + 7 * rank                      # the reference's seed rule (train_gan.py:56)
     torch.manual_seed(seed)
     c, h, w, n = args.channels, args.height, args.width, args.batch
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.float8_e4m3fn}[args.dtype]
 
     torch.manual_seed(333)                     # identical initial weights on every rank (DDP also broadcasts)
     import contextlib
@@ -303,6 +308,8 @@ def main():
 
     note(f"models built, {args.warmup} warm-up steps")
     nxt = (lambda i: feed.next()) if feed is not None else (lambda i: batches[i % 2])
+    if args.dtype == "fp8":          # first exponents of the quantisation sites (state-neutral; un-timed)
+        trainer.calibrate_fp8(*(batches[0] if batches is not None else feed.next()))
     for i in range(args.warmup):
         trainer.step(*nxt(i))
     sync_all()
@@ -393,10 +400,12 @@ def main():
         # below it the same kernel is an HBM-bound copy with some arithmetic attached (the 128-channel 1x1 layers of the
         # entry flow: 64 FLOP/B) and belongs under the HBM roofline: those launches are listed as '<entry point>[hbm]'
         # with their algorithmic GB/s and are not part of the MFMA figure.
-        ridge = (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3) * 1e12 / 8e12
+        def peak_of(name):   # the MFMA peak of the operand type an entry point computes on
+            return PEAK_FP8_TFLOPS if name.endswith("_fp8") else PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS
+        ridge = peak_of("") * 1e12 / 8e12
         fam = {}
         for name, flops, e0, e1, nbytes in recs:
-            if name.startswith("bg_conv2d") and nbytes > 0 and flops / nbytes < ridge:
+            if name.startswith("bg_conv2d") and nbytes > 0 and flops / nbytes < peak_of(name) * 1e12 / 8e12:
                 name += "[hbm]"
             f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
             f[0] += 1
@@ -421,12 +430,14 @@ def main():
         achieved = flops / secs * 1e-12
         walg = w_alg_tflop(h, w, c, args.loss)
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom, "ridge_flop_per_byte": ridge, "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
-            "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": traffic,
+            "bound": "mfma", "kernel": dom, "ridge_flop_per_byte": peak_of(dom) * 1e12 / 8e12, "achieved": achieved, "peak": peak_of(dom),
+            "unit": "TFLOP/s", "frac": achieved / peak_of(dom), "traffic": traffic,
             "traffic_source": None if traffic is None else "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "command (profiles/*_pmc_hbm_traffic.json); not re-measured in this run",
             "launches": cnt, "avg_launch_ms": 1e3 * secs / cnt, "alg_gflop_per_launch": flops / cnt * 1e-9,
             "step_conv_stack_tflops": None if walg is None else value / world * walg,
+            # whole conv stack against the bf16 peak (the north_star's figure; an fp8 run is quoted against it too -- its
+            # weight gradients and the layers below the fp8 threshold compute in bf16)
             "step_conv_stack_frac": None if walg is None else value / world * walg / PEAK_BF16_TFLOPS,
             # per entry point: MFMA-bound ones in TFLOP/s, HBM-bound ones in algorithmic GB/s (peak 8000)
             "families": {k: {"launches": v[0], "total_ms": 1e3 * v[1], "tflops": (v[2] / v[1] * 1e-12 if v[1] > 0 else 0.0),
