@@ -64,6 +64,8 @@ _SIGS = {
     "bg_conv2d_bwd_data_fp8": [C.POINTER(ConvDesc), c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_fwd": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_data": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
+    "bg_dwconv3x3_bwd_fused": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp,
+                               c_vp, c_vp],
     "bg_dwconv3x3_bwd_weight": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_data_add": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
     "bg_dwconv3x3_fwd_pre": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
@@ -235,6 +237,9 @@ def _alg_bytes(name, a) -> float:
         es = _es(d.dtype)
         wbytes = d.Cout * d.Cin * d.KH * d.KW * (4 if name == "bg_conv2d_bwd_weight" else es)
         return float(d.N) * (d.H * d.W * d.Cin + d.Ho * d.Wo * d.Cout) * es + wbytes
+    if name == "bg_dwconv3x3_bwd_fused":      # dy in, x in, da out
+        d = a[0]
+        return float(d.N) * 3 * d.H * d.W * d.C * _es(d.dtype)
     if name == "bg_dwconv3x3_bwd_data_add":   # dy in, addend in, dx out
         d = a[0]
         return float(d.N) * 3 * d.H * d.W * d.C * _es(d.dtype)

@@ -132,12 +132,38 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Geometry of the epilogue's transposition buffer: one 16-pixel x (MI*16-channel) block per wave, UNPADDED rows of
+// CHB bytes, bank-conflict free on both sides (scripts/lds_conflicts.py, the LDS model of MI355X_MICROARCH.md):
+//   writer  lane (pixel r16, channel quad q) stores its 4 channels of fragment i (8 B bf16: ds_write_b64, serviced in
+//           16-lane groups = 16 pixels at ONE channel offset; 16 B fp32: ds_write_b128, 8-lane groups);
+//   reader  lane takes 16-byte chunk ci = t*64 + lane of the block, pixel-major (ds_read_b128).
+// With padded rows (16 bytes, round 2) the bf16 writer hit every bank twice and the reader's lane groups wrapped onto
+// each other (SQ_LDS_BANK_CONFLICT 9-21 % of the LDS cycles of every GEMM variant).  Here the chunk index inside a
+// pixel's row is XORed with a function of the pixel -- pix & 7 where a row is a multiple of 8 chunks, (pix >> 1) & 3
+// otherwise (the XOR then stays inside aligned groups of 4 chunks) -- and, for the 8-byte granules of bf16, the two
+// halves of a chunk are exchanged for pixels 8-15 (the reader swaps them back): 16 pixels -> 16 distinct bank pairs.
+template <int CPP, int ES>
+struct EpiSwz {
+    static constexpr bool WIDE = CPP % 8 == 0;
+    static_assert(CPP % 4 == 0, "the XOR must stay inside a pixel's row: rows of whole 4-chunk groups");
+    __device__ static __forceinline__ int f(int pix) { return WIDE ? (pix & 7) : ((pix >> 1) & 3); }
+    __device__ static __forceinline__ bool flip(int pix) { return ES == 2 && (pix & 8); }
+    // byte offset inside the region of (pixel, byte b of its row): b is a multiple of the writer's granule
+    __device__ static __forceinline__ int wr(int pix, int b) {
+        const int gr = ES == 2 ? 8 : 16;
+        int within = b & 15;
+        if (ES == 2 && flip(pix)) within ^= gr;
+        return pix * (CPP * 16) + (((b >> 4) ^ f(pix)) << 4) + within;
+    }
+    __device__ static __forceinline__ int rd(int pix, int ch) { return pix * (CPP * 16) + ((ch ^ f(pix)) << 4); }
+};
+
 template <typename T, int MI, int NJ, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4 (&acc)[MI][NJ], int p_base, int rows_valid,
                                                   int grp, int c_base, int wave_c, int wave_p, int lane, char* smem) {
     constexpr int TM = WM * MI * 16, ES = (int)sizeof(T);
     constexpr int CHB = MI * 16 * ES;      // bytes of one pixel's channels in this wave's sub-tile
-    constexpr int ROWB = CHB + 16;         // padded LDS row
+    constexpr int ROWB = CHB;              // unpadded LDS row, swizzled (EpiSwz)
     constexpr int CPP = CHB / 16;          // 16-byte chunks per pixel
     constexpr int NST = 16 * CPP / 64;     // store instructions per 16-pixel block
     constexpr int REGION = 16 * ROWB;
@@ -157,11 +183,13 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
 
     // read-back geometry: chunk ci of the block's 16 * CPP is (pixel ci / CPP, 16-byte chunk ci % CPP)
     int rd_off[NST], st_coff[NST], st_pix[NST];
+    bool rd_flip[NST];
 #pragma unroll
     for (int t = 0; t < NST; ++t) {
         const int ci = t * 64 + lane;
         const int pix = ci / CPP, ch = ci - pix * CPP;
-        rd_off[t] = pix * ROWB + ch * 16;
+        rd_off[t] = EpiSwz<CPP, ES>::rd(pix, ch);
+        rd_flip[t] = EpiSwz<CPP, ES>::flip(pix);
         const int co = c_base + wave_c * MI * 16 + ch * (16 / ES);
         st_coff[t] = co < P.NO ? co * ES : OOB;      // Cout is a multiple of the 16-byte vector
         st_pix[t] = wave_p * NJ * 16 + pix;
@@ -179,7 +207,9 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
-    const int wr_off = r16 * ROWB + q * 4 * ES;
+    int wr_off[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) wr_off[i] = EpiSwz<CPP, ES>::wr(r16, i * 16 * ES + q * 4 * ES);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -188,7 +218,7 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
             if (P.bias) v += bv[i];
             if constexpr (sizeof(T) == 2) {
                 const bf16x4 ov = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *reinterpret_cast<bf16x4*>(region + wr_off + i * 16 * ES) = ov;
+                *reinterpret_cast<bf16x4*>(region + wr_off[i]) = ov;
                 if (stats) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -198,7 +228,7 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
                     }
                 }
             } else {
-                *reinterpret_cast<f32x4*>(region + wr_off + i * 16 * ES) = v;
+                *reinterpret_cast<f32x4*>(region + wr_off[i]) = v;
                 if (stats) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -211,7 +241,8 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
         // the region is private to the wave and a wave's LDS instructions execute in order: no barrier
 #pragma unroll
         for (int t = 0; t < NST; ++t) {
-            const u32x4 w = *reinterpret_cast<const u32x4*>(region + rd_off[t]);
+            u32x4 w = *reinterpret_cast<const u32x4*>(region + rd_off[t]);
+            if (ES == 2 && rd_flip[t]) w = u32x4{w[2], w[3], w[0], w[1]};
             const int row = st_pix[t] + j * 16;
             const int roff = row < rows_valid ? row * P.ldo * ES : OOB;
             const int off = (roff | st_coff[t]) < 0 ? OOB : roff + st_coff[t];
@@ -257,7 +288,7 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
                                                        int grp, int c_base, int wave_c, int wave_p, int lane, char* smem) {
     constexpr int TM = WM * MI * 16, ES = (int)sizeof(T);
     constexpr int CHB = MI * 16 * ES;      // bytes of one pixel's channels in this wave's sub-tile
-    constexpr int ROWB = CHB + 16;         // padded LDS row
+    constexpr int ROWB = CHB;              // unpadded LDS row, swizzled (EpiSwz)
     constexpr int CPP = CHB / 16;          // 16-byte chunks per pixel
     constexpr int NST = 16 * CPP / 64;     // store instructions per 16-pixel block
     constexpr int REGION = 16 * ROWB;
@@ -277,11 +308,13 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
 
     // read-back geometry: chunk ci of the block's 16 * CPP is (pixel ci / CPP, 16-byte chunk ci % CPP)
     int rd_off[NST], st_coff[NST], st_pix[NST];
+    bool rd_flip[NST];
 #pragma unroll
     for (int t = 0; t < NST; ++t) {
         const int ci = t * 64 + lane;
         const int pix = ci / CPP, ch = ci - pix * CPP;
-        rd_off[t] = pix * ROWB + ch * 16;
+        rd_off[t] = EpiSwz<CPP, ES>::rd(pix, ch);
+        rd_flip[t] = EpiSwz<CPP, ES>::flip(pix);
         const int co = c_base + wave_c * MI * 16 + ch * (16 / ES);
         st_coff[t] = co < P.NO ? co * ES : OOB;      // Cout is a multiple of the 16-byte vector
         st_pix[t] = wave_p * NJ * 16 + pix;
@@ -291,7 +324,9 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
-    const int wr_off = r16 * ROWB + q * 4 * ES;
+    int wr_off[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) wr_off[i] = EpiSwz<CPP, ES>::wr(r16, i * 16 * ES + q * 4 * ES);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -299,7 +334,7 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
             const f32x4 v = acc[i][j];
             if constexpr (sizeof(T) == 2) {
                 const bf16x4 ov = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *reinterpret_cast<bf16x4*>(region + wr_off + i * 16 * ES) = ov;
+                *reinterpret_cast<bf16x4*>(region + wr_off[i]) = ov;
                 if (stats) {
                     // the stored values back as fp32 straight from the two packed dwords (one shift / one mask per
                     // value instead of a conversion and a shift), accumulated as pairs (v_pk_add_f32 / v_pk_fma_f32)
@@ -316,7 +351,7 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
                     }
                 }
             } else {
-                *reinterpret_cast<f32x4*>(region + wr_off + i * 16 * ES) = v;
+                *reinterpret_cast<f32x4*>(region + wr_off[i]) = v;
                 if (stats) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -329,7 +364,8 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
         // the region is private to the wave and a wave's LDS instructions execute in order: no barrier
 #pragma unroll
         for (int t = 0; t < NST; ++t) {
-            const u32x4 w = *reinterpret_cast<const u32x4*>(region + rd_off[t]);
+            u32x4 w = *reinterpret_cast<const u32x4*>(region + rd_off[t]);
+            if (ES == 2 && rd_flip[t]) w = u32x4{w[2], w[3], w[0], w[1]};
             const int row = st_pix[t] + j * 16;
             const int roff = row < rows_valid ? row * P.ldo * ES : OOB;
             const int off = (roff | st_coff[t]) < 0 ? OOB : roff + st_coff[t];

@@ -165,18 +165,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedParams P) {
                 r = P.rstd ? P.rstd[(long long)g * P.C + cg] : 1.f;
                 norm_affine(P.gamma ? P.gamma[cg] : 1.f, P.beta ? P.beta[cg] : 0.f, m, r, a, b);
             }
-            red[ch] = m;
-            red[row_w + ch] = r;
-            red[2 * row_w + ch] = a;
-            red[3 * row_w + ch] = b;
+            const int ti = (ch % VEC) * P.tx + ch / VEC;   // element-major: conflict-free reads, see norm_act_fwd_kernel
+            red[ti] = m;
+            red[row_w + ti] = r;
+            red[2 * row_w + ti] = a;
+            red[3 * row_w + ti] = b;
         }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            mu[e] = red[lx * VEC + e];
-            rs[e] = red[row_w + lx * VEC + e];
-            sc[e] = red[2 * row_w + lx * VEC + e];
-            sh[e] = red[3 * row_w + lx * VEC + e];
+            mu[e] = red[e * P.tx + lx];
+            rs[e] = red[row_w + e * P.tx + lx];
+            sc[e] = red[2 * row_w + e * P.tx + lx];
+            sh[e] = red[3 * row_w + e * P.tx + lx];
         }
         __syncthreads();
     }
@@ -484,8 +485,12 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
                     b = P.shift[i];
                 }
             }
-            s_sc[ch] = a;
-            s_sh[ch] = b;
+            // stored element-major ([e][lx]): the read below is then one conflict-free ds_read_b32 per element, lanes
+            // consecutive (lane-major rows of 8 floats put 16 lanes on the same banks: SQ_LDS_BANK_CONFLICT 0.8 of the
+            // few LDS cycles of these kernels in round 2)
+            const int ti = (ch % VEC) * P.tx + ch / VEC;
+            s_sc[ti] = a;
+            s_sh[ti] = b;
         }
     }
     __syncthreads();
@@ -493,8 +498,8 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        sc[e] = s_sc[lx * VEC + e];
-        sh[e] = s_sh[lx * VEC + e];
+        sc[e] = s_sc[e * P.tx + lx];
+        sh[e] = s_sh[e * P.tx + lx];
     }
     const T* x = reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c;
     const T* res = RES ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
@@ -628,11 +633,12 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
                     cc0 = useB ? P.Cc[i] : 0.f;
                 }
             }
-            ew_tab[ch] = a;
-            ew_tab[row_w + ch] = b;
-            ew_tab[2 * row_w + ch] = cc0;
-            ew_tab[3 * row_w + ch] = s;
-            ew_tab[4 * row_w + ch] = h;
+            const int ti = (ch % VEC) * P.tx + ch / VEC;   // element-major, see norm_act_fwd_kernel
+            ew_tab[ti] = a;
+            ew_tab[row_w + ti] = b;
+            ew_tab[2 * row_w + ti] = cc0;
+            ew_tab[3 * row_w + ti] = s;
+            ew_tab[4 * row_w + ti] = h;
         }
     }
     __syncthreads();
@@ -640,11 +646,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
     float ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        ca[e] = ew_tab[lx * VEC + e];
-        cb[e] = ew_tab[row_w + lx * VEC + e];
-        cc[e] = ew_tab[2 * row_w + lx * VEC + e];
-        sc[e] = ew_tab[3 * row_w + lx * VEC + e];
-        sh[e] = ew_tab[4 * row_w + lx * VEC + e];
+        ca[e] = ew_tab[e * P.tx + lx];
+        cb[e] = ew_tab[row_w + e * P.tx + lx];
+        cc[e] = ew_tab[2 * row_w + e * P.tx + lx];
+        sc[e] = ew_tab[3 * row_w + e * P.tx + lx];
+        sh[e] = ew_tab[4 * row_w + e * P.tx + lx];
     }
     constexpr bool LDX = USEB || SIGN == 2;
     const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;

@@ -159,6 +159,7 @@ def wgrad_join(key=None):
 # dW tile in registers over a whole layer).  BGAMD_WGRAD_GROUP=0 restores the per-layer launches.
 _WG_GROUPS = {}
 _WG_GROUP_ENABLED = _os.environ.get("BGAMD_WGRAD_GROUP", "1") != "0"
+_WG_CHUNK = int(_os.environ.get("BGAMD_WGG_CHUNK", "0"))   # layers per grouped launch issued DURING the pass (0: all at its end)
 
 
 def wgrad_group_ok(dtype, kh, kw, stride, pad, dil, has_bias) -> bool:
@@ -178,7 +179,12 @@ def wgrad_group_add(dev, x, g, dw_ptr, rows, cin, cout, desc):
         return
     _wg_register(key)
     sig = (rows, cin, cout, ld_of(x), ld_of(g))
-    _WG_GROUPS.setdefault(key, {}).setdefault(sig, []).append((x, g, dw_ptr, desc))
+    jobs = _WG_GROUPS.setdefault(key, {}).setdefault(sig, [])
+    jobs.append((x, g, dw_ptr, desc))
+    if _WG_CHUNK and len(jobs) >= _WG_CHUNK:
+        # issue the group's launch now, on the side stream: its (MFMA / LDS-bound, one workgroup per CU) workgroups run
+        # under the HBM-bound normalisation / depthwise kernels of the data-gradient chain instead of after the pass
+        wgrad_group_flush(key, sig)
 
 
 def _gang_pays(n_layers, cin, cout) -> bool:
@@ -195,8 +201,12 @@ def _gang_shape_ok(cin, cout) -> bool:
     return cin * cout >= 0.7 * tiles * 65536
 
 
-def wgrad_group_flush(key):
-    groups = _WG_GROUPS.pop(key, None)
+def wgrad_group_flush(key, only_sig=None):
+    if only_sig is None:
+        groups = _WG_GROUPS.pop(key, None)
+    else:
+        jobs_ = _WG_GROUPS.get(key, {}).pop(only_sig, None)
+        groups = {only_sig: jobs_} if jobs_ else None
     if not groups:
         return
     dev = torch.device("cuda", key)
@@ -757,6 +767,7 @@ class NormActFn(torch.autograd.Function):
         return (dx, dres) + (None,) * 15
 
 
+_DW_FUSED_BWD = _os.environ.get("BGAMD_DW_FUSED_BWD", "1") != "0"   # A/B switch: 0 = the three separate backward kernels
 _FOLD_FINALIZE = _os.environ.get("BGAMD_NO_FOLD_FINALIZE") is None and _os.environ.get("BGAMD_DW_RING", "1") != "0"   # A/B switch
 
 
@@ -812,22 +823,33 @@ class NormActDwConvFn(torch.autograd.Function):
         n, h, w, c = x.shape
         dev, dt = x.device, L.dt(x.dtype)
         rows = n * h * w
-        if ctx.needs_input_grad[3]:
-            arena.ensure_grad(wslot)
-            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-            wgrad_call(dev, (x, g, scale, shift), "bg_dwconv3x3_bwd_weight_pre", desc, x.data_ptr(), scale.data_ptr(),
-                       shift.data_ptr(), groups, act, g.data_ptr(), arena.grad_ptr(wslot))
         need_dx = ctx.needs_input_grad[0]
         want_affine_grads = gslot.param.requires_grad
+        fused = (_DW_FUSED_BWD and x.dtype == torch.bfloat16 and (need_dx or want_affine_grads)
+                 and h * w * max(ld_of(x), ld_of(g)) * 2 < (1 << 31))
+        if ctx.needs_input_grad[3]:
+            arena.ensure_grad(wslot)
+            if not fused:
+                desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+                wgrad_call(dev, (x, g, scale, shift), "bg_dwconv3x3_bwd_weight_pre", desc, x.data_ptr(), scale.data_ptr(),
+                           shift.data_ptr(), groups, act, g.data_ptr(), arena.grad_ptr(wslot))
         if not (need_dx or want_affine_grads):
             return (None,) * 16
         da = new_act(n, h, w, c, x.dtype, dev)   # gradient of the activated tensor
-        desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(da), ld_of(g))
-        L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), da.data_ptr())
         gptr, bptr = arena.master_ptr(gslot), arena.master_ptr(bslot)
         s = _f64(2, groups, c, device=dev)
-        L.call("bg_norm_act_bwd_reduce", dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x), mean.data_ptr(),
-               rstd.data_ptr(), gptr, bptr, rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
+        if fused:
+            # ONE pass over g and x: the depthwise data gradient, the depthwise weight gradient on the recomputed activation
+            # and the two statistics of the BatchNorm backward (three launches and six tensor passes in round 2)
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+            L.call("bg_dwconv3x3_bwd_fused", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), scale.data_ptr(),
+                   shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), groups, act, da.data_ptr(), ld_of(da),
+                   arena.grad_ptr(wslot) if ctx.needs_input_grad[3] else None, s[0].data_ptr(), s[1].data_ptr())
+        else:
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(da), ld_of(g))
+            L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), da.data_ptr())
+            L.call("bg_norm_act_bwd_reduce", dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x), mean.data_ptr(),
+                   rstd.data_ptr(), gptr, bptr, rows, c, groups, act, s[0].data_ptr(), s[1].data_ptr())
         dg = db = None
         if want_affine_grads:
             arena.ensure_grad(gslot)

@@ -192,6 +192,19 @@ int bg_dwconv3x3_fwd_pre_stats(const bg_dwconv_desc* d, const void* x, const dou
                                float* running_var, float* mean, float* rstd, float* scale, float* shift, int32_t groups,
                                int32_t act, const void* w, void* y, void* stream);
 
+/* Backward of the fused unit above in ONE pass over its two inputs (bf16): from dy (gradient w.r.t. the depthwise
+ * output, pixel stride d->ldy) and x (the raw convolution output the forward kernel normalised, pixel stride d->ldx):
+ *   da = depthwise data gradient of dy (gradient w.r.t. the activated tensor; pixel stride ldda; what
+ *        bg_dwconv3x3_bwd_data writes), dw += the depthwise weight gradient on the recomputed activation (what
+ *        bg_dwconv3x3_bwd_weight_pre adds; NULL: skipped), s1 / s2 (fp64 [groups, C], caller zeroes) += the two
+ *        statistics of the BatchNorm backward (what bg_norm_act_bwd_reduce adds with y = NULL: sum g, sum g * xhat with
+ *        g = da * act'(x * scale + shift), xhat = (x - mean) * rstd, da as stored).
+ * scale / shift / mean / rstd: fp32 [groups, C] of the forward pass.  Stride 1, dilation 1 or 2.  Replaces three launches
+ * and six tensor passes by three passes; bg_norm_act_bwd_apply_stats follows as before. */
+int bg_dwconv3x3_bwd_fused(const bg_dwconv_desc* d, const void* dy, const void* w, const void* x, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, int32_t groups, int32_t act, void* da,
+                           int32_t ldda, float* dw, double* s1, double* s2, void* stream);
+
 /* ---------------------------------------------------------------------------
  * 3-D DeepLab GAN path (architecture/gpsro/deeplab3d.py).  A volume [N,D,H,W,C] is the
  * NHWC tensor [N*D,H,W,C]; every entry point above applies to it as it stands.  The third dimension adds:

@@ -1082,3 +1082,73 @@ def test_conv_split_k(case, dtype):
     if bad is not None:
         with pytest.raises(RuntimeError, match="non-empty"):
             L.call("bg_conv2d_fwd_splitk", desc, xv.data_ptr(), wpk.data_ptr(), ws.data_ptr(), bad)
+
+
+@pytest.mark.parametrize("with_dw", [True, False])
+@pytest.mark.parametrize("case", [(4, 13, 18, 16, 1, 2, 1), (2, 9, 7, 728, 1, 1, 1), (4, 16, 12, 24, 2, 2, 1), (2, 6, 5, 40, 1, 1, 0),
+                                  (2, 11, 50, 264, 1, 1, 2), (2, 72, 48, 728, 1, 1, 1), (2, 37, 101, 136, 2, 1, 1), (3, 5, 130, 72, 1, 3, 1)])
+def test_dwconv_bwd_fused_matches_the_three_kernels(case, with_dw):
+    """bg_dwconv3x3_bwd_fused (one pass over dy and x: data gradient, weight gradient on the recomputed activation and
+    the two BatchNorm-backward statistics) against the three round-2 kernels it replaces -- bg_dwconv3x3_bwd_data,
+    bg_dwconv3x3_bwd_weight_pre, bg_norm_act_bwd_reduce -- on the same bf16 tensors.  The data gradient is the same nine
+    fp32 products per element summed in another order, then rounded to bf16: equal to bf16 rounding (1 ulp = 2^-8
+    relative, on a few elements); weight gradient and statistics sum the same terms over the pixels in another order:
+    2e-5 of their max.  Also against torch in fp32 (1e-2 of max, the bf16 kernel bound)."""
+    n, h, w, c, d, groups, act = case
+    dtype = torch.bfloat16
+    cp = up(c, dtype)
+    x = (rnd((n, c, h, w), 71, dtype, 2.0) + 0.4).to(dtype).float()
+    wt = rnd((c, 1, 3, 3), 72, dtype, 0.3)
+    go = rnd((n, c, h, w), 73, dtype)
+    ld = cp + 8
+    (xb, xv), (gb, gv) = to_nhwc(x, dtype, ld, 8), to_nhwc(go, dtype, ld, 8)
+    wk = torch.zeros(3, 3, cp, dtype=dtype, device=DEV)
+    wk[:, :, :c] = wt[:, 0].permute(1, 2, 0).to(dtype).to(DEV)
+    rows, dtc = n * h * w, L.dt(dtype)
+    gamma = (torch.rand(cp) - 0.3).to(DEV)
+    beta = (torch.randn(cp) * 0.2).to(DEV)
+    f32 = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    f64 = lambda *s: torch.zeros(*s, device=DEV, dtype=torch.float64)  # noqa: E731
+    s, ss = f64(groups, cp), f64(groups, cp)
+    L.call("bg_norm_stats", dtc, xv.data_ptr(), rows, cp, ld, groups, s.data_ptr(), ss.data_ptr())
+    mean, rstd, scale, shift = f32(groups, cp), f32(groups, cp), f32(groups, cp), f32(groups, cp)
+    L.call("bg_norm_finalize_affine", s.data_ptr(), ss.data_ptr(), rows // groups, groups, cp, gamma.data_ptr(), beta.data_ptr(),
+           1e-5, 0.1, None, None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    # the three separate kernels
+    ldd = cp + 16
+    da0 = torch.full((n, h, w, ldd), 3.0, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_bwd_data", L.DwDesc(dtc, n, h, w, cp, h, w, 1, d, ldd, ld), gv.data_ptr(), wk.data_ptr(), da0.data_ptr())
+    dw0 = f32(3, 3, cp)
+    L.call("bg_dwconv3x3_bwd_weight_pre", L.DwDesc(dtc, n, h, w, cp, h, w, 1, d, ld, ld), xv.data_ptr(), scale.data_ptr(),
+           shift.data_ptr(), groups, act, gv.data_ptr(), dw0.data_ptr())
+    s1a, s2a = f64(groups, cp), f64(groups, cp)
+    L.call("bg_norm_act_bwd_reduce", dtc, da0.data_ptr(), ldd, None, 0, xv.data_ptr(), ld, mean.data_ptr(), rstd.data_ptr(),
+           gamma.data_ptr(), beta.data_ptr(), rows, cp, groups, act, s1a.data_ptr(), s2a.data_ptr())
+    # the fused kernel
+    da1 = torch.full((n, h, w, ldd), 3.0, dtype=dtype, device=DEV)
+    dw1 = f32(3, 3, cp)
+    s1b, s2b = f64(groups, cp), f64(groups, cp)
+    L.call("bg_dwconv3x3_bwd_fused", L.DwDesc(dtc, n, h, w, cp, h, w, 1, d, ld, ld), gv.data_ptr(), wk.data_ptr(), xv.data_ptr(),
+           scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), groups, act, da1.data_ptr(), ldd,
+           dw1.data_ptr() if with_dw else None, s1b.data_ptr(), s2b.data_ptr())
+    torch.cuda.synchronize()
+    assert (da1[..., cp:].float() == 3.0).all(), "lanes beyond C were written"
+    a, b = da0[..., :cp].float().cpu(), da1[..., :cp].float().cpu()
+    assert (a - b).abs().max().item() <= 2.0 ** -7 * a.abs().max().item(), (a - b).abs().max().item()
+    assert ((a != b).float().mean().item()) < 2e-2, "more than 2 % of the elements round differently"
+    ref = torch.nn.grad.conv2d_input((n, c, h + 2 * d, w + 2 * d), wt, go, 1, 0, d, groups=c)[:, :, d:d + h, d:d + w]
+    assert_close(from_nhwc(da1, c), ref, 1e-2, "fused data gradient vs torch")
+    if with_dw:
+        assert_close(dw1.cpu(), dw0.cpu(), 2e-5, "fused depthwise weight gradient")
+    else:
+        assert (dw1 == 0).all()
+    # statistics: the fused kernel sums g from ITS stored da; where da rounds differently (<= 1 bf16 ulp on < 2 % of the
+    # elements) the sums move by that much
+    assert_close(s1b.cpu(), s1a.cpu(), 2e-4, "sum g")
+    assert_close(s2b.cpu(), s2a.cpu(), 2e-4, "sum g * xhat")
+    # ... and exactly (2e-5) against the separate reduction run on the fused kernel's own da
+    s1c, s2c = f64(groups, cp), f64(groups, cp)
+    L.call("bg_norm_act_bwd_reduce", dtc, da1.data_ptr(), ldd, None, 0, xv.data_ptr(), ld, mean.data_ptr(), rstd.data_ptr(),
+           gamma.data_ptr(), beta.data_ptr(), rows, cp, groups, act, s1c.data_ptr(), s2c.data_ptr())
+    assert_close(s1b.cpu(), s1c.cpu(), 2e-5, "sum g vs the reduction of the same da")
+    assert_close(s2b.cpu(), s2c.cpu(), 2e-5, "sum g * xhat vs the reduction of the same da")
