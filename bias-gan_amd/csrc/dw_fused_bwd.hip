@@ -21,7 +21,10 @@ constexpr int FB_OOB = (int)0x80000000;
 constexpr int FB_SLAB = 64;        // channels per slab: 128 bytes per pixel
 constexpr int FB_ITEMS = 16;       // 4-channel items per slab = lanes along channels
 constexpr int FB_THREADS = 512;
-constexpr int FB_PL = FB_THREADS / FB_ITEMS;   // pixel lanes per workgroup: 32
+constexpr int FB_NWAVE = FB_THREADS / 64;
+constexpr int FB_PL = FB_THREADS / FB_ITEMS;   // pixel lanes per workgroup: 32 = 4 rows x 8 columns per iteration
+constexpr int FB_TW = 24;          // output columns per tile (3 column groups of 8)
+constexpr int FB_PITCH = 32;       // pixels per staged dA row: FB_TW + 2 D, padded to whole 8-pixel pieces
 
 struct DwFusedParams {
     const bf16_t* g;     // dA: gradient w.r.t. the depthwise output [N, H, W, C], pixel stride ldg
@@ -35,12 +38,9 @@ struct DwFusedParams {
     float* dw;           // [3][3][C] fp32, accumulated (NULL: weights frozen)
     double* s1;          // [groups][C] += sum g
     double* s2;          // [groups][C] += sum g * xhat
-    int N, H, W, C, ldg, ldx, ldda, D, ipg;
+    int N, H, W, C, ldg, ldx, ldda, ipg;
     float slope;
-    int slabs, R, TW, tiles_h, tiles_w, tiles, bps;
-    int buf_bytes;   // one tile buffer (two of them, then the statistics scratch)
-    int dpad;        // pixels of the dA part of a buffer (tile + halo, rounded up to 8); the z part (R x TW pixels) follows
-    int zpad;        // pixels of the z part, rounded up to 8
+    int slabs, tiles_h, tiles_w, tiles, bps;
 };
 
 __device__ __forceinline__ void fb_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset) {
@@ -57,13 +57,38 @@ __device__ __forceinline__ void unpack4(const s16x4 v, float (&f)[4]) {
     f[3] = __uint_as_float(p[1] & 0xffff0000u);
 }
 
-template <bool WG>
+// Geometry (compile time per dilation D): a tile is R output rows x 24 columns x 64 channels; its dA part is staged with
+// the halo as (R + 2D) rows of 32 pixels (24 + 2D, padded to whole 8-pixel pieces), its z part as R rows of 24 pixels;
+// two such buffers.  The 32 pixel lanes of the workgroup cover 4 rows x 8 columns per iteration, R/4 x 3 iterations per
+// tile, fully unrolled: every LDS address is a per-thread base plus an immediate, every global address a per-thread
+// offset into a descriptor the scalar unit rebases -- no integer multiply and no division on the vector unit inside the
+// loop (the first version spent more than half of its issue slots there: SQ_ACTIVE_INST_ANY 0.49 per wave at two waves
+// per SIMD, i.e. issue-bound at 2.4 TB/s).
+template <int D> struct FbGeo {
+    static constexpr int R = D == 1 ? 8 : 4;
+    static constexpr int THP = R + 2 * D;
+    static constexpr int DPIX = THP * FB_PITCH;         // staged dA pixels
+    static constexpr int ZPIX = R * FB_TW;              // staged z pixels
+    static constexpr int NPD = DPIX / 8, NPZ = ZPIX / 8;   // 8-pixel pieces
+    static constexpr int PPW = (NPD + NPZ + FB_NWAVE - 1) / FB_NWAVE;   // pieces per wave and tile
+    static constexpr int ITERS = (R / 4) * 3;
+    static constexpr int PPI = (PPW + ITERS - 1) / ITERS;               // pieces issued per pixel iteration
+    static constexpr int BUF_BYTES = (DPIX + ZPIX) * 128;
+    static constexpr int RED_BYTES = 2 * FB_PL * FB_SLAB * 4;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES + RED_BYTES + FB_NWAVE * 1024;
+    static_assert(FB_TW + 2 * D <= FB_PITCH && R % 4 == 0, "tile geometry");
+    static_assert(LDS_BYTES <= 160 * 1024 && 9 * FB_PL * FB_SLAB * 4 <= 2 * BUF_BYTES, "LDS budget");
+};
+
+template <bool WG, int D>
 __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams P) {
+    typedef FbGeo<D> G;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     extern __shared__ __align__(16) char fb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // blocks sharing id % 8 share an XCD: give every XCD a contiguous range of (tile, slab) so that the slabs of one
-    // pixel range (whose 128-byte pieces share cache lines) and adjacent row tiles (which share halo rows) meet in one L2
+    // pixel range (whose 128-byte pieces share cache lines) and adjacent tiles (which share halo pixels) meet in one L2
     int lin = blockIdx.x;
     {
         const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = lin & 7, k = lin >> 3;
@@ -71,12 +96,10 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
     }
     const int slab = lin % P.slabs, tb = lin / P.slabs;
     const int it = tid & (FB_ITEMS - 1), pl = tid >> 4;
+    const int pr = pl >> 3, pc = pl & 7;                 // this thread's pixel inside an iteration's 4 x 8 group
     const int c0 = slab * FB_SLAB + it * 4;
     const bool c_ok = c0 < P.C;   // C is a multiple of 8: a 4-channel item is all inside or all outside
-    const int D = P.D, TWp = P.TW + 2 * D, THp = P.R + 2 * D;
-    const int tile_pix = THp * TWp;
     const int per_img = P.tiles_h * P.tiles_w;
-    constexpr int NWAVE = FB_THREADS / 64;
 
     float wf[9][4], dwa[9][4], a1[4], a2[4];
 #pragma unroll
@@ -92,7 +115,8 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
     float sc[4], sh[4], rs[4], mo[4];
     int cur_g = -1;
     char* const buf0 = fb_smem;
-    float* const red_s = reinterpret_cast<float*>(fb_smem + 2 * P.buf_bytes);   // statistics scratch, apart from the tile buffers
+    float* const red_s = reinterpret_cast<float*>(fb_smem + 2 * G::BUF_BYTES);   // statistics scratch, apart from the tile buffers
+    char* const dump = fb_smem + 2 * G::BUF_BYTES + G::RED_BYTES + wave * 1024;
 
     // block reduction of per-thread partial sums over the pixel lanes, one atomic per channel and value
     auto flush_stats = [&](int g) {
@@ -114,64 +138,67 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
         }
     };
 
-    // Staging of one dA tile with its halo: 8 pixels (x 128 B) per wave instruction, lanes beyond the image, the tile or
-    // C fetch zeros (out-of-range offsets).  A tile's pieces are issued ONE OR TWO PER PIXEL ITERATION of the tile before
-    // it (into the other buffer), so that the loads the compute loop waits for are never queued behind a burst.
-    // Every call issues exactly ONE wave instruction (once the tile is complete: an out-of-range fetch into a per-wave dump
-    // area), so the number of operations younger than any load is the same on every path and the compiler's counted
-    // s_waitcnt vmcnt(N) for that load never includes a piece issued after it.  (With a conditional issue the counter
-    // logic must assume the shortest path and the wave then waits for the fresh piece too: measured, every pixel
-    // iteration paid a memory round trip.)
-    __amdgpu_buffer_rsrc_t d_rg, d_rx;
-    const int stage_pix = P.dpad + P.zpad;   // piece index space of one tile: dA with its halo, then z
-    int d_base = stage_pix, d_row0 = 0, d_col0 = 0;
-    char* d_dst = buf0;
-    char* const dump = fb_smem + 2 * P.buf_bytes + 2 * FB_PL * FB_SLAB * 4 + wave * 1024;
-    const int piece = lane & 7;
+    // ---- staging: piece k of a tile = 8 pixels x 128 B = one wave instruction; pieces 0 .. NPD-1 are the dA tile with
+    // its halo (row k / 4, pixels (k % 4) * 8 ..), NPD .. NPD+NPZ-1 the z tile (row kz / 3, pixels (kz % 3) * 8 ..).
+    // Wave w issues pieces w, w + 8, ...: row and column of a piece are wave-uniform (scalar unit), the descriptor is
+    // rebased to the piece's first pixel, a lane adds its own constant offset and is switched off (out-of-range offset:
+    // the DMA writes zeros) outside the image or beyond C.  Every call issues exactly ONE wave instruction -- once the
+    // tile is complete an out-of-range fetch into a per-wave dump area -- so the number of operations younger than any
+    // other is the same on every path (the compiler's counted waits never include a freshly issued piece).
+    const int lp = lane >> 3, piece = lane & 7;
     const bool ch_ok = slab * FB_SLAB + piece * 8 < P.C;
-    const float inv_twp = 1.f / (float)TWp, inv_tw = 1.f / (float)P.TW;
-    const unsigned g_bytes = (unsigned)(((long long)P.H * P.W - 1) * P.ldg + P.C) * 2u;
-    const unsigned x_bytes = (unsigned)(((long long)P.H * P.W - 1) * P.ldx + P.C) * 2u;
-    // (the descriptors must always be valid: the dump fetches use them too)
-    d_rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.g), 0, (int)g_bytes, 0x00020000);
-    d_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.x), 0, (int)x_bytes, 0x00020000);
+    const int lane_g = ch_ok ? (lp * P.ldg + slab * FB_SLAB + piece * 8) * 2 : FB_OOB;   // byte offset of this lane inside a dA piece
+    const int lane_x = ch_ok ? (lp * P.ldx + slab * FB_SLAB + piece * 8) * 2 : FB_OOB;
+    const char* d_bg = reinterpret_cast<const char*>(P.g);   // first staged pixel of the tile being staged: (row0 - D, col0 - D) of dA
+    const char* d_bx = reinterpret_cast<const char*>(P.x);   // ... (row0, col0) of z
+    int d_row0 = 0, d_col0 = 0;
+    bool d_on = false;
+    char* d_dst = buf0;
     auto dma_begin = [&](int tile_, char* dst) {
         const int n = tile_ / per_img, rem = tile_ - n * per_img;
         const int th = rem / P.tiles_w, tw = rem - th * P.tiles_w;
-        d_rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.g + (long long)n * P.H * P.W * P.ldg), 0, (int)g_bytes, 0x00020000);
-        d_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P.x + (long long)n * P.H * P.W * P.ldx), 0, (int)x_bytes, 0x00020000);
-        d_row0 = th * P.R; d_col0 = tw * P.TW;
-        d_base = wave * 8;
+        d_row0 = th * G::R; d_col0 = tw * FB_TW;
+        d_bg = reinterpret_cast<const char*>(P.g) + (((long long)n * P.H + d_row0 - D) * P.W + d_col0 - D) * P.ldg * 2;
+        d_bx = reinterpret_cast<const char*>(P.x) + (((long long)n * P.H + d_row0) * P.W + d_col0) * P.ldx * 2;
         d_dst = dst;
+        d_on = true;
     };
-    auto dma_piece = [&]() {
-        const bool live = d_base < stage_pix;   // wave-uniform
-        const bool isz = d_base >= P.dpad;      // wave-uniform: dpad is a multiple of 8
-        int voff = FB_OOB;
-        if (!isz) {
-            const int pi = d_base + (lane >> 3);
-            const int tr = (int)(((float)pi + 0.5f) * inv_twp), tc = pi - tr * TWp;   // exact: pi < 2^12
-            const int ih = d_row0 - D + tr, iw = d_col0 - D + tc;
-            const bool ok = live && ch_ok && tr < THp && (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W;
-            if (ok) voff = ((ih * P.W + iw) * P.ldg + slab * FB_SLAB + piece * 8) * 2;
-            fb_dma16(d_rg, live ? d_dst + d_base * 128 : dump, voff);
-        } else {
-            const int pi = d_base - P.dpad + (lane >> 3);
-            const int tr = (int)(((float)pi + 0.5f) * inv_tw), tc = pi - tr * P.TW;
-            const int ih = d_row0 + tr, iw = d_col0 + tc;
-            const bool ok = live && ch_ok && tr < P.R && ih < P.H && iw < P.W;
-            if (ok) voff = ((ih * P.W + iw) * P.ldx + slab * FB_SLAB + piece * 8) * 2;
-            fb_dma16(d_rx, live ? d_dst + d_base * 128 : dump, voff);
-        }
-        d_base += 8 * NWAVE;
+    // Piece k of a part (dA: NPD pieces, row k / 4, pixels (k % 4) * 8 ..; z: NPZ pieces, row k / 3, pixels (k % 3) * 8 ..)
+    // is issued by wave k % 8 as its slot k / 8; slots are compile-time constants at every call site, the rest is a
+    // handful of scalar operations (32-bit: a tile spans < 2^31 bytes).
+    int wv = wave;   // re-materialised per tile (below): the slot arithmetic stays inside the tile loop instead of 50 hoisted scalars
+    auto dma_a = [&](int j) {
+        const int k = wv + FB_NWAVE * j;       // wave-uniform
+        const int tr = k >> 2, px = (k & 3) * 8;
+        const bool live = d_on && k < G::NPD;
+        const char* base = d_bg + (tr * P.W + px) * P.ldg * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+        const bool ok = live && (unsigned)(d_row0 - D + tr) < (unsigned)P.H && (unsigned)(d_col0 - D + px + lp) < (unsigned)P.W;
+        fb_dma16(rs, live ? d_dst + k * 1024 : dump, ok ? lane_g : FB_OOB);
     };
-    const int pieces_per_wave = (stage_pix + 8 * NWAVE - 1) / (8 * NWAVE);
+    auto dma_z = [&](int j) {
+        const int k = wv + FB_NWAVE * j;
+        const int tr = (k * 43) >> 7, px = (k - tr * 3) * 8;          // k / 3 (k < 128)
+        const bool live = d_on && k < G::NPZ;
+        const char* base = d_bx + (tr * P.W + px) * P.ldx * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+        const bool ok = live && d_row0 + tr < P.H && d_col0 + px + lp < P.W;
+        fb_dma16(rs, live ? d_dst + (G::NPD + k) * 1024 : dump, ok ? lane_x : FB_OOB);
+    };
+    constexpr int SLOTS_A = (G::NPD + FB_NWAVE - 1) / FB_NWAVE, SLOTS_Z = (G::NPZ + FB_NWAVE - 1) / FB_NWAVE;
+    constexpr int APER = (SLOTS_A + G::ITERS - 1) / G::ITERS, ZPER = (SLOTS_Z + G::ITERS - 1) / G::ITERS;   // per pixel iteration
 
     int tile = tb, cur = 0;
     if (tile < P.tiles) {
         dma_begin(tile, buf0);
-        for (int k = 0; k < pieces_per_wave; ++k) dma_piece();
+#pragma unroll
+        for (int j = 0; j < SLOTS_A; ++j) dma_a(j);
+#pragma unroll
+        for (int j = 0; j < SLOTS_Z; ++j) dma_z(j);
     }
+    // per-thread LDS bases inside a buffer (immediates do the rest)
+    const int lds_tap = ((pr + 2 * D) * FB_PITCH + pc + 2 * D) * 128 + it * 8;
+    const int lds_z = G::DPIX * 128 + (pr * FB_TW + pc) * 128 + it * 8;
     for (; tile < P.tiles; tile += P.bps) {
         const int n = tile / per_img, rem = tile - n * per_img;
         const int th = rem / P.tiles_w, tw = rem - th * P.tiles_w;
@@ -190,36 +217,38 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
                 for (int e = 0; e < 4; ++e) { sc[e] = 0.f; sh[e] = 0.f; rs[e] = 0.f; mo[e] = 0.f; }
             }
         }
-        const int row0 = th * P.R, col0 = tw * P.TW;
-        const int rows_out = min(P.R, P.H - row0), cols_out = min(P.TW, P.W - col0);
-        const long long img_pix = (long long)n * P.H * P.W;
+        const int row0 = th * G::R, col0 = tw * FB_TW;
         // this tile has landed (this wave's pieces: the counter; every wave's: the barrier), and every wave has left the
         // previous tile, whose buffer the next tile's pieces may now overwrite
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* tbuf = buf0 + cur * P.buf_bytes;
+        asm volatile("" : "+s"(wv));
+        const char* tbuf = buf0 + cur * G::BUF_BYTES;
         const bool has_next = tile + P.bps < P.tiles;
-        if (has_next) dma_begin(tile + P.bps, buf0 + (cur ^ 1) * P.buf_bytes);
-        else d_base = stage_pix;   // nothing to stage: the pieces go to the dump
-        {
-            const int npix = rows_out * cols_out;
-            const int iters = (npix + FB_PL - 1) / FB_PL;   // the same for every thread: one load, one piece, one store per iteration
-            const float inv_c = 1.f / (float)cols_out;
-            const unsigned dbytes = (unsigned)(((long long)P.H * P.W - 1) * P.ldda + P.C) * 2u;
-            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(P.da + img_pix * P.ldda, 0, (int)dbytes, 0x00020000);
-            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-            const char* zbuf = tbuf + P.dpad * 128 + it * 8;
-            int p = pl;
-            int r = (int)(((float)p + 0.5f) * inv_c), c = p - r * cols_out;
-            for (int i = 0; i < iters; ++i) {
-                const bool ok = p < npix;
-                const int pn = p + FB_PL;
-                const int rn = (int)(((float)pn + 0.5f) * inv_c), cn = pn - rn * cols_out;
-                dma_piece();   // two pieces of the next tile per iteration, always issued (static operation counts)
-                dma_piece();
-                if (!ok) { r = 0; c = 0; }   // stay inside the tile buffer; the contributions are masked below
+        if (has_next) dma_begin(tile + P.bps, buf0 + (cur ^ 1) * G::BUF_BYTES);
+        else d_on = false;   // nothing to stage: the pieces go to the dump
+        // the output descriptor rebased to the tile's first pixel; a thread's offset inside it is fixed per iteration
+        const long long tile_pix0 = ((long long)n * P.H + row0) * P.W + col0;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(P.da + tile_pix0 * P.ldda, 0, 0x7fffffff, 0x00020000);
+        const char* tap0 = tbuf + lds_tap;
+        const char* z0 = tbuf + lds_z;
+        const int rmax = c_ok ? P.H - row0 - pr : 0, cmax = P.W - col0 - pc;   // this thread's pixel exists while rg*4 < rmax, cg*8 < cmax
+        const int d_thread = ((pr * P.W + pc) * P.ldda + c0) * 2;
+        int nrg = G::R / 4;
+        if (WG) asm volatile("" : "+s"(nrg));   // the weight-gradient variant keeps its row groups a loop: unrolled, its 36 more
+                                                // accumulators push the allocation over 256 registers (measured: 125 spills)
+#pragma unroll
+        for (int rg = 0; rg < nrg; ++rg) {
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) {
+                __builtin_amdgcn_sched_barrier(0);   // one iteration's loads are not hoisted into the previous one (registers)
+                const bool ok = rg * 4 < rmax && cg * 8 < cmax;
+#pragma unroll
+                for (int q = 0; q < APER; ++q) dma_a((rg * 3 + cg) * APER + q);   // slots beyond the part: dump fetches
+#pragma unroll
+                for (int q = 0; q < ZPER; ++q) dma_z((rg * 3 + cg) * ZPER + q);
                 float z[4], u[4], av[4];
-                unpack4(*reinterpret_cast<const s16x4*>(zbuf + (r * P.TW + c) * 128), z);
+                unpack4(*reinterpret_cast<const s16x4*>(z0 + rg * (4 * FB_TW * 128) + cg * 8 * 128), z);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     u[e] = fmaf(z[e], sc[e], sh[e]);
@@ -231,12 +260,11 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
                     if (!ok) av[0] = av[1] = av[2] = av[3] = 0.f;
                 }
                 float dacc[4] = {0.f, 0.f, 0.f, 0.f};
-                const char* wbase = tbuf + ((r + 2 * D) * TWp + c + 2 * D) * 128 + it * 8;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int tr = t / 3, tc = t - tr * 3;
                     float v[4];
-                    unpack4(*reinterpret_cast<const s16x4*>(wbase - (tr * TWp + tc) * D * 128), v);
+                    unpack4(*reinterpret_cast<const s16x4*>(tap0 + rg * (4 * FB_PITCH * 128) + ((-tr * D) * FB_PITCH + cg * 8 - tc * D) * 128), v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         dacc[e] = fmaf(v[e], wf[t][e], dacc[e]);
@@ -244,7 +272,7 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
                     }
                 }
                 const bf16x4 db = {(bf16_t)dacc[0], (bf16_t)dacc[1], (bf16_t)dacc[2], (bf16_t)dacc[3]};
-                const int doff = (c_ok && ok) ? (((row0 + r) * P.W + col0 + c) * P.ldda + c0) * 2 : FB_OOB;
+                const int doff = ok ? d_thread + (rg * 4 * P.W + cg * 8) * P.ldda * 2 : FB_OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, db), rd, doff, 0, 0);
                 float dr[4];
                 unpack4(__builtin_bit_cast(s16x4, db), dr);   // the gradient as stored: what the second pass will read
@@ -254,9 +282,7 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
                     a1[e] += gg;
                     a2[e] = fmaf(gg, fmaf(z[e], rs[e], mo[e]), a2[e]);
                 }
-                p = pn; r = rn; c = cn;
             }
-            for (int k = 2 * iters; k < pieces_per_wave; ++k) dma_piece();   // ragged tiles: whatever is left of the next tile
         }
         cur ^= 1;
     }
@@ -280,6 +306,16 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
     }
 }
 
+template <bool WG, int D>
+void fb_launch(const DwFusedParams& P, hipStream_t st) {
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<WG, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL((dw_bwd_fused_kernel<WG, D>), dim3((unsigned)(P.slabs * P.bps)), dim3(FB_THREADS), FbGeo<D>::LDS_BYTES, st, P);
+}
+
 }  // namespace
 
 extern "C" int bg_dwconv3x3_bwd_fused(const bg_dwconv_desc* d, const void* dy, const void* w, const void* x, const float* scale,
@@ -299,42 +335,20 @@ extern "C" int bg_dwconv3x3_bwd_fused(const bg_dwconv_desc* d, const void* dy, c
     P.g = (const bf16_t*)dy; P.x = (const bf16_t*)x; P.w = (const bf16_t*)w;
     P.scale = scale; P.shift = shift; P.mean = mean; P.rstd = rstd;
     P.da = (bf16_t*)da; P.dw = dw; P.s1 = s1; P.s2 = s2;
-    P.N = d->N; P.H = d->H; P.W = d->W; P.C = d->C; P.ldg = d->ldy; P.ldx = d->ldx; P.ldda = ldda; P.D = d->dil;
+    P.N = d->N; P.H = d->H; P.W = d->W; P.C = d->C; P.ldg = d->ldy; P.ldx = d->ldx; P.ldda = ldda;
     P.ipg = d->N / groups;
     P.slope = act == 0 ? 1.f : act == 2 ? 0.f : LRELU_SLOPE;
     P.slabs = (d->C + FB_SLAB - 1) / FB_SLAB;
     // tile shape: at most max_pix staged pixels (128 B each); the (rows, columns) with the least halo per output pixel
-    // tile shape: dA tile with halo + z tile (128 B per pixel) in one buffer of at most max_pix pixels, two buffers;
-    // the (rows, columns) with the least halo per output pixel
-    static const int max_pix = getenv("BGAMD_FB_PIX") ? atoi(getenv("BGAMD_FB_PIX")) : 512;
-    const int D = P.D;
-    double best = 1e30;
-    for (int tw = std::min(8, P.W); tw <= std::min(P.W, 96); ++tw) {
-        int r = std::min(P.H, (max_pix - 2 * D * (tw + 2 * D)) / (2 * tw + 2 * D));   // (r + 2D)(tw + 2D) + r tw <= max_pix
-        while (r >= 1 && ((r + 2 * D) * (tw + 2 * D) + 7) / 8 * 8 + (r * tw + 7) / 8 * 8 > max_pix) --r;
-        if (r < 1) continue;
-        const int th_ = (P.H + r - 1) / r, tw_ = (P.W + tw - 1) / tw;
-        const double staged = (double)th_ * tw_ * (r + 2 * D) * (tw + 2 * D);   // dA pixels moved into LDS per image
-        if (staged < best) { best = staged; P.R = r; P.TW = tw; P.tiles_h = th_; P.tiles_w = tw_; }
-    }
-    BG_CHECK_ARG(best < 1e30, "bg_dwconv3x3_bwd_fused: no tile shape");
+    const int R = d->dil == 1 ? FbGeo<1>::R : FbGeo<2>::R;
+    P.tiles_h = (P.H + R - 1) / R;
+    P.tiles_w = (P.W + FB_TW - 1) / FB_TW;
     P.tiles = P.N * P.tiles_h * P.tiles_w;
     static const int target = getenv("BGAMD_FB_BLOCKS") ? atoi(getenv("BGAMD_FB_BLOCKS")) : 256;   // one workgroup per CU walking its tiles
     P.bps = std::max(1, std::min(P.tiles, target / P.slabs));
-    P.dpad = ((P.R + 2 * D) * (P.TW + 2 * D) + 7) / 8 * 8;
-    P.zpad = (P.R * P.TW + 7) / 8 * 8;
-    P.buf_bytes = (P.dpad + P.zpad) * 128;
-    const size_t lds = std::max<size_t>((size_t)2 * P.buf_bytes + (size_t)2 * FB_PL * FB_SLAB * 4 + (FB_THREADS / 64) * 1024, (size_t)9 * FB_PL * FB_SLAB * 4);
-    BG_CHECK_ARG(lds <= 160 * 1024, "bg_dwconv3x3_bwd_fused: tile too large for the LDS");
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
-    const dim3 grid((unsigned)(P.slabs * P.bps));
-    if (dw) hipLaunchKernelGGL(dw_bwd_fused_kernel<true>, grid, dim3(FB_THREADS), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(dw_bwd_fused_kernel<false>, grid, dim3(FB_THREADS), lds, (hipStream_t)stream, P);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dil == 1) { if (dw) fb_launch<true, 1>(P, st); else fb_launch<false, 1>(P, st); }
+    else { if (dw) fb_launch<true, 2>(P, st); else fb_launch<false, 2>(P, st); }
     BG_CHECK_LAUNCH("dw_bwd_fused_kernel");
     return BG_OK;
 }

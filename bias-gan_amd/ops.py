@@ -825,8 +825,12 @@ class NormActDwConvFn(torch.autograd.Function):
         rows = n * h * w
         need_dx = ctx.needs_input_grad[0]
         want_affine_grads = gslot.param.requires_grad
+        # the one-pass kernel (bg_dwconv3x3_bwd_fused) wherever the depthwise weight gradient is wanted: measured 1.5-1.9x
+        # the three kernels at dilation 1, 1.15-1.2x at dilation 2 (scripts/bench_dwfused.py); with frozen weights (the
+        # G-step's pass through D) it only beats the remaining two kernels on large tensors at dilation 1
         fused = (_DW_FUSED_BWD and x.dtype == torch.bfloat16 and (need_dx or want_affine_grads)
-                 and h * w * max(ld_of(x), ld_of(g)) * 2 < (1 << 31))
+                 and h * w * max(ld_of(x), ld_of(g)) * 2 < (1 << 31)
+                 and (ctx.needs_input_grad[3] or (dil == 1 and rows * c >= 150_000_000)))
         if ctx.needs_input_grad[3]:
             arena.ensure_grad(wslot)
             if not fused:

@@ -8,6 +8,8 @@ from bias_gan_amd import _lib as L
 
 SHAPES = [(728, 72, 48, 1), (728, 144, 96, 1), (256, 288, 192, 1), (128, 576, 384, 1), (1536, 72, 48, 2), (1024, 72, 48, 1)]
 batches = [int(a) for a in sys.argv[1:]] or [8, 16]
+if os.environ.get("ONE"):
+    SHAPES = SHAPES[:1]
 
 
 def timeit(fn, reps=10):

@@ -9,7 +9,7 @@ calls = collections.Counter()
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
         name = row["Kernel_Name"]
-        key = next((k for k in ("gemm_conv_fat_kernel", "wgrad_gang_kernel", "gemm_conv_dma_kernel", "wgrad_kernel", "dw_ring_kernel", "dw_s1_kernel", "dw_bwd_weight", "norm_act_fwd",
+        key = next((k for k in ("gemm_conv_fat_kernel", "wgrad_gang_kernel", "gemm_conv_dma_kernel", "wgrad_kernel", "dw_bwd_fused_kernel", "dw_ring_kernel", "dw_s1_kernel", "dw_bwd_weight", "norm_act_fwd",
                                 "norm_act_bwd_apply", "colreduce") if k in name), None)
         if key is None:
             continue
