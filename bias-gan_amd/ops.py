@@ -352,13 +352,22 @@ def _splitk_finish(ws, y):
 
 
 # ---- fp8 operand path (BASELINE.json configs[4]; include/bgamd.h "fp8 operand path") --------------------------------
-def fp8_layer_ok(arena: Arena, wslot: ParamSlot, kh, kw) -> bool:
-    """Which dense convolutions take fp8 operands: reductions of at least 256 (below that the launch is an HBM-bound copy
-    whatever the operand type) onto at least 64 output channels."""
+_FP8_MIN_WORK = int(_os.environ.get("BGAMD_FP8_MIN_WORK", "1500"))
+
+
+def fp8_layer_ok(arena: Arena, wslot: ParamSlot, kh, kw, grad: bool = False, prequantised: bool = False) -> bool:
+    """Which dense convolutions take fp8 operands.  The operand must first be quantised (3 bytes per element moved by
+    bg_quant_fp8 unless the producer wrote the fp8 copy itself); the GEMM then saves ~35 % of its bf16 time.  Per element
+    of the operand the saving grows with the taps x channels on the OTHER side of the GEMM (Cout for the forward pass,
+    Cin for the data gradient): measured break-even at ~900 (a 728 -> 728 pointwise layer: 49 us saved, 53 us of
+    quantisation, scripts/bench_fp8.py), so layers below BGAMD_FP8_MIN_WORK = 1500 stay on bf16 operands unless the fp8
+    copy already exists.  Reductions below 256 or fewer than 64 channels on either side: never (HBM-bound copies)."""
     if not getattr(arena, "fp8", False) or wslot.f8 is None:
         return False
     kp, _, _, cp = wslot.phys_shape
-    return cp * kh * kw >= 256 and kp >= 64 and cp >= 64
+    if not (cp * kh * kw >= 256 and kp >= 64 and cp >= 64):
+        return False
+    return prequantised or kh * kw * (cp if grad else kp) >= _FP8_MIN_WORK
 
 
 def fp8_quant(t: torch.Tensor, fmt: int, exp_ptr: int, amax_ptr: int) -> torch.Tensor:
@@ -394,13 +403,13 @@ class Conv2dFn(torch.autograd.Function):
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
         splits = splitk_plan(n * ho * wo, kp, cin, kh, kw, x.dtype) if bslot is None else 0
-        use8 = x.dtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw)
+        xq = getattr(x, "_bg_fp8", None)
+        use8 = x.dtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw, prequantised=xq is not None)
         if use8:
             # fp8 operands: the input's e4m3 copy (the producer's, if it made one; else one quantisation pass) against the
             # arena's e4m3 weights; bf16 output and statistics as below.  Until the sites have been calibrated (the first
             # training step) the GEMM stays on bf16 and the quantiser only records the input's max |value|.
             ep, ap = arena.site_ptrs(wslot, grad=False)
-            xq = getattr(x, "_bg_fp8", None)
             if xq is None or xq[1] != ep or not arena.sites_ready:
                 xq = (fp8_quant(x, L.FP8_E4M3, ep, ap), ep)
             use8 = arena.sites_ready
@@ -447,10 +456,11 @@ class Conv2dFn(torch.autograd.Function):
             dx = new_act(n, h, w, cin, xdtype, xdev)
             d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(dx), ld_of(g))
             splits = splitk_plan(n * h * w, cin, kp, kh, kw, xdtype)
-            use8 = xdtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw) and cin >= 64
+            gq = getattr(g, "_bg_fp8", None)
+            use8 = (xdtype == torch.bfloat16 and not splits and cin >= 64
+                    and fp8_layer_ok(arena, wslot, kh, kw, grad=True, prequantised=gq is not None))
             if use8:
                 ep, ap = arena.site_ptrs(wslot, grad=True)
-                gq = getattr(g, "_bg_fp8", None)
                 if gq is None or gq[1] != ep or not arena.sites_ready:
                     gq = (fp8_quant(g, L.FP8_E5M2, ep, ap), ep)
                 use8 = arena.sites_ready

@@ -278,6 +278,7 @@ def test_fp8_mode_uses_the_fp8_kernels_after_calibration(monkeypatch):
     launches as the bf16 path plus the quantiser.  From the second step on the eligible convolutions launch
     bg_conv2d_fwd_fp8 / bg_conv2d_bwd_data_fp8.  Counted through the library's launch profile hook."""
     monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    monkeypatch.setattr(ops, "_FP8_MIN_WORK", 0)      # every eligible layer (the default keeps the narrow ones on bf16 operands)
     c, h, w, n = 4, 64, 64, 2
     G, D, _, _ = build(c, h, w, FP8)
     tr, _ = trainer(G, D, n)
@@ -317,11 +318,12 @@ def test_calibrate_fp8_leaves_the_training_state_untouched():
     assert G.arena().sites_ready and D.arena().sites_ready and int((G.arena().site_exp != 0).sum()) > 50
 
 
-def test_blocks_teacher_forced_fp8():
+def test_blocks_teacher_forced_fp8(monkeypatch):
     """Per-Block error of the fp8 operand path without the cascade (the bf16 version is test_parity_gpu.py's
     test_blocks_teacher_forced_bf16): each Xception block of the generator gets the fp32 oracle's input and its output
     is compared with the oracle's.  e4m3 carries 3 mantissa bits (relative step 2^-4 .. 2^-3, rms ~ 2.5 % per operand);
     a block chains 3-4 pointwise GEMMs on such operands.  Bounds = 2 x the largest value measured (printed with -s)."""
+    monkeypatch.setattr(ops, "_FP8_MIN_WORK", 0)      # every eligible layer on fp8 operands, the middle flow included
     c, h, w, n = 16, 64, 96, 2
     spec = orc.generator_spec(c, c, 0, "batch")
     G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d, compute_dtype=FP8)
@@ -357,6 +359,7 @@ def test_fp8_first_iteration_vs_oracle(mode, monkeypatch):
     on the same seeded inputs and labels, next to the bf16 path's distance from the same oracle.  The randomly filled
     140-layer nets amplify storage rounding (bf16 end-to-end: ~1e-1); fp8 operands add to it."""
     monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    monkeypatch.setattr(ops, "_FP8_MIN_WORK", 0)
     c, h, w, n = 4, 64, 64, 2
     x, y = orc.synthetic_fields(n, c, h, w, 1000)
     res = {}
