@@ -577,9 +577,11 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
     auto piece = [&](int buf, int pi) {   // pi is a compile-time constant at every call site (unrolled loops)
         char* stage_a = smem + buf * STAGE_BYTES + wave * 16 * BKB;
         if (pi < SA * PPS) {
+#ifndef ABL_FAT_NO_A   // ablation (scripts/ablate_fat.sh): no A-operand traffic at all -- the bound of "weights through VGPRs"
             const int s_ = pi / PPS, h = pi % PPS;
             dma16(rs_w, stage_a + (s_ * 128 + h * RPG) * BKB, va[s_][h]);
             va[s_][h] += BKB;   // an out-of-range marker stays out of range
+#endif
         } else {
             const int s_ = (pi - SA * PPS) / PPS, h = (pi - SA * PPS) % PPS;
             dma16(rs_in, stage_a + A_BYTES + (s_ * 128 + h * RPG) * BKB, (last_ks && tail_cut[h]) ? OOB : vb[s_][h]);
@@ -688,7 +690,11 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
                 bf16x8 b[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q));
+#ifdef ABL_FAT_NO_A
+                bf16x8 a = b[0];
+#else
                 bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + r16, ks * 4 + q));
+#endif
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -698,7 +704,11 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
                             if ((ks * MI + i) * PPG + e < GROUP) piece(nbuf, (ks * MI + i) * PPG + e);
                     }
                     bf16x8 an = a;
+#ifdef ABL_FAT_NO_A
+                    if (i + 1 < MI) an = b[(i + 1) % NJ];
+#else
                     if (i + 1 < MI) an = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + (i + 1) * 16 + r16, ks * 4 + q));
+#endif
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);

@@ -150,8 +150,8 @@ def test_c5_full_size_step_fp8_vs_oracle():
     b16, f8 = res[torch.bfloat16], res[torch.float8_e4m3fn]
     assert all(np.isfinite(v) for v in f8)
     assert _rel(b16[0], d_ref) <= 2e-1 and _rel(b16[1], g_ref) <= 2e-1 and b16[2] <= 2e-1     # measured 1.0e-2, 9.1e-3
-    # fp8, 2 x measured: d_loss 3.0e-1, g_loss 5.5e-1 (see the docstring: sign agreement of D's first Adam step)
-    assert _rel(f8[0], d_ref) <= 6e-1 and _rel(f8[1], g_ref) <= 1.1 and f8[2] <= FP8_FAKE_BOUND
-
-
-FP8_FAKE_BOUND = 6e-1    # generator output rms-rel: set to 2 x the value the first run prints
+    # fp8 with the default layer rule (ops.fp8_layer_ok: operands in fp8 where the quantisation pass pays -- the exit flow,
+    # the ASPP, the decoder's 3 x 3 layers), 2 x measured: generator output 1.54e-1 (bf16: 1.18e-1), d_loss 1.25e-1,
+    # g_loss 1.09e-1.  With EVERY eligible layer on fp8 operands (BGAMD_FP8_MIN_WORK=0) the same run measured d_loss
+    # 3.0e-1, g_loss 5.5e-1: the docstring's accumulation through ~70 layers.
+    assert _rel(f8[0], d_ref) <= 2.5e-1 and _rel(f8[1], g_ref) <= 2.2e-1 and f8[2] <= 3.1e-1
