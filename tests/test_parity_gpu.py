@@ -1107,7 +1107,9 @@ def test_blocks_teacher_forced_bf16_backward():
     """The BACKWARD of every Xception Block in bf16, teacher-forced: each block gets the fp32 oracle's
     input and the oracle's output gradient for that block (both rounded to bf16 at the boundary); its input gradient and
     its parameter gradients are compared with the oracle's fp32 autograd on the same block.  rms-rel bounds = 2 x the
-    largest value measured over the 20 blocks (printed with -s)."""
+    largest value measured over the 20 blocks (printed with -s).  (The backward of a block is an order of magnitude
+    further from fp32 than its forward -- 3-5e-2 against 3-6e-3 -- on these maps: 4 x 6 pixels x 2 images per channel,
+    so every BatchNorm backward subtracts two 48-sample means of bf16-rounded gradients.)"""
     import torch.nn.functional as F
     c, h, w, n = 16, 64, 96, 2
     G, spec = build_generator(c, 7, BF16)
@@ -1156,4 +1158,4 @@ def test_blocks_teacher_forced_bf16_backward():
     assert worst_dx <= BF16_BWD_DX and worst_dp <= BF16_BWD_DP, (worst_dx, worst_dp)
 
 
-BF16_BWD_DX, BF16_BWD_DP = 1e-1, 2e-1     # set from the first run on the box (2 x measured)
+BF16_BWD_DX, BF16_BWD_DP = 1.05e-1, 1.9e-1     # 2 x measured: dx 2.3e-2 .. 5.2e-2 (block4), parameter gradients 4.6e-2 .. 9.3e-2 (block18)
