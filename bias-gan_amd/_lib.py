@@ -46,6 +46,8 @@ _HOST_SIGS = {
     "bg_ring_acquire": [c_vp, c_i64, c_vp, C.POINTER(c_vp)],
     "bg_ring_copy_out": [c_vp, c_i64, c_vp, c_i64, c_vp],
     "bg_ring_release": [c_vp, c_i64, c_vp],
+    "bg_stream_create": [C.POINTER(c_vp)],
+    "bg_stream_destroy": [c_vp],
 }
 
 # name -> argtypes (restype is int for all but bg_last_error); mirrors include/bgamd.h
@@ -319,3 +321,21 @@ def call(name, *args):
         rc = fn(*args, stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.bg_last_error().decode()}")
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, tag: str):
+    """The package's dedicated side stream `tag` on `device` (created once, never shared with PyTorch's stream pool -- see
+    bg_stream_create): a torch.cuda.ExternalStream over a HIP stream the library owns."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, tag)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        out = c_vp()
+        with torch.cuda.device(idx):
+            host_call("bg_stream_create", C.byref(out))
+        s = _SIDE_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", idx))
+    return s

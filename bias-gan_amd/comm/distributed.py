@@ -16,6 +16,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .. import _lib as _L
+
 
 class FlatAllReduce:
     """SUM all-reduce of one flat tensor in `bucket_elems`-sized pieces on a side
@@ -26,7 +28,7 @@ class FlatAllReduce:
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, int(bucket_elems))
         self.cuda = flat.is_cuda
-        self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.stream = _L.side_stream(flat.device, f"allreduce-{id(self)}") if self.cuda else None
         self.works = []
         self.launched = False
 

@@ -15,6 +15,7 @@ import torch
 from ..architecture.gpsro import deeplab_gan as dxg
 from ..comm.distributed import DistributedModel
 from .. import ops
+from .._lib import side_stream as _side_stream
 from ..graphs import NoGradGraph
 from ..runtime import StatsPool
 
@@ -72,7 +73,7 @@ class GANTrainer:
             n = outputs_real.shape[0]
             if self._want_g_ahead:
                 if self._side == "auto":
-                    self._side = torch.cuda.Stream(device=inputs.device)
+                    self._side = _side_stream(inputs.device, "generator-ahead")
                 if self._side is not None:
                     self._side.wait_stream(torch.cuda.current_stream(inputs.device))
                     with torch.cuda.stream(self._side):
@@ -81,7 +82,7 @@ class GANTrainer:
                 logits, _ = self.discriminator((outputs_real, outputs_fake))
             return self._d_update(logits[:n], logits[n:], outputs_fake, outputs_real, labels, eta)
         if self._side == "auto":
-            self._side = torch.cuda.Stream(device=inputs.device) if inputs.is_cuda else None
+            self._side = _side_stream(inputs.device, "generator-ahead") if inputs.is_cuda else None
         if self._side is not None:
             main = torch.cuda.current_stream(inputs.device)
             self._side.wait_stream(main)

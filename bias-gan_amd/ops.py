@@ -131,7 +131,7 @@ def wgrad_call(dev, tensors, name, *args):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _WG_STREAMS.get(key)
     if ent is None:
-        side = torch.cuda.Stream(device=dev)
+        side = L.side_stream(dev, "wgrad")
         ent = _WG_STREAMS[key] = (side, side.cuda_stream)
     side, raw = ent
     side.wait_stream(torch.cuda.current_stream(dev))
@@ -214,7 +214,7 @@ def wgrad_group_flush(key, only_sig=None):
     if use_side:
         ent = _WG_STREAMS.get(key)
         if ent is None:
-            side = torch.cuda.Stream(device=dev)
+            side = L.side_stream(dev, "wgrad")
             ent = _WG_STREAMS[key] = (side, side.cuda_stream)
         side, raw = ent
         side.wait_stream(torch.cuda.current_stream(dev))

@@ -59,6 +59,11 @@ extern "C" {
 
 int bg_abi_version(void);
 const char* bg_last_error(void);
+/* A dedicated non-blocking HIP stream on the current device (host-side call; *out receives the hipStream_t).  The host
+ * mirror wraps these (torch.cuda.ExternalStream) for its side work instead of taking streams from PyTorch's shared pool
+ * of 32 per device, in which two side streams may be the same HIP stream. */
+int bg_stream_create(void** out);
+int bg_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------
  * Dense convolution as implicit GEMM on MFMA (nn.Conv2d with groups=1:

@@ -1159,3 +1159,41 @@ def test_blocks_teacher_forced_bf16_backward():
 
 
 BF16_BWD_DX, BF16_BWD_DP = 1.05e-1, 1.9e-1     # 2 x measured: dx 2.3e-2 .. 5.2e-2 (block4), parameter gradients 4.6e-2 .. 9.3e-2 (block18)
+
+
+def test_side_streams_are_dedicated_not_pool_streams():
+    """The package's side streams (weight gradients, early generator forward, all-reduce) are HIP streams of their own
+    (bg_stream_create), never taken from torch.cuda.Stream()'s pool of 32 per device.  Round 3 found why that matters: the
+    33rd Stream() of a process IS the first one again; when a trainer's generator-ahead stream was the same HIP stream as
+    the weight-gradient stream, a forked capture stream waited on itself during the whole-step capture and
+    hip::Stream::EndCapture recursed until the stack overflowed -- a segmentation fault that appeared only after enough
+    earlier tests had created trainers."""
+    from bias_gan_amd import _lib as L
+    a, b = L.side_stream(DEV, "wgrad"), L.side_stream(DEV, "generator-ahead")
+    assert a.cuda_stream != b.cuda_stream and L.side_stream(DEV, "wgrad") is a
+    pool = {torch.cuda.Stream().cuda_stream for _ in range(70)}
+    assert len(pool) == 32, "torch's pool size changed: revisit the comment in csrc/api.hip"
+    assert a.cuda_stream not in pool and b.cuda_stream not in pool
+    # ... and the scenario itself: 40 trainers (each asks for its generator-ahead stream), then a captured step
+    import os
+    c, h, w, n = 4, 64, 64, 2
+    G, _ = build_generator(c, 41, F32)
+    D, _ = build_discriminator(c, h, w, 42, F32)
+    G.train(), D.train()
+    crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+    old = os.environ.get("BGAMD_STEP_GRAPH")
+    os.environ["BGAMD_STEP_GRAPH"] = "1"
+    try:
+        for k in range(3):       # streams drawn from the pool in between, as other code in the process would
+            [torch.cuda.Stream() for _ in range(11)]
+            tr = GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 0.0, 1e-8, 0.0), ph.get_optimizer(D.parameters(), "Adam", 0.0, 1e-8, 0.0),
+                            crit, losses.L1Loss())
+            x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 700))
+            for _ in range(4):
+                d_loss, g_loss = tr.step(x, y)
+            assert len(tr._graphs) == 1 and np.isfinite(float(d_loss)) and np.isfinite(float(g_loss))
+    finally:
+        if old is None:
+            os.environ.pop("BGAMD_STEP_GRAPH", None)
+        else:
+            os.environ["BGAMD_STEP_GRAPH"] = old
