@@ -333,6 +333,8 @@ def side_stream(device, tag: str):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, tag)
     s = _SIDE_STREAMS.get(key)
+    if s is None and os.environ.get("BGAMD_POOL_STREAMS"):   # A/B switch only: PyTorch's pool streams (may alias each other)
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", idx))
     if s is None:
         out = c_vp()
         with torch.cuda.device(idx):

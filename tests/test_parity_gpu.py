@@ -1100,7 +1100,7 @@ def test_generator_adam_moments_teacher_forced(dtype):
         assert devs[int(0.9 * len(devs))] <= BF16_TF_90 and worst <= BF16_TF_WORST, (devs[int(0.9 * len(devs))], worst, worst_name)
 
 
-BF16_TF_90, BF16_TF_WORST = 0.5, 2.0     # set from the first run on the box (2 x measured)
+BF16_TF_90, BF16_TF_WORST = 3.9e-1, 1.2     # 2 x measured: median 9.3e-2, 90 % of the parameters 1.9e-1, worst 5.9e-1 (the last bias)
 
 
 def test_blocks_teacher_forced_bf16_backward():
