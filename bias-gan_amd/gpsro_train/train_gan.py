@@ -42,6 +42,7 @@ class GANTrainer:
         self._d_pending = False
         self._gp = gradient_penalty_fn or dxg.gradient_penalty
         self._train_d = self._train_g = True   # False: evaluate the losses only (train_gan3d.py's update schedule)
+        self._always_eval = False              # True (3-D loop): both losses are evaluated every iteration, the flags gate the updates
         self.d_loss_scale = 1.0                # train_gan3d.py:306 multiplies d_loss by loss_weight_gan
         self.last_d_acc = None                 # 0.5 * (acc(real) + acc(fake)) of the last D-step (device scalar)
         # the generator forward of the D-step has no data dependence on D(real): run them on two HIP
@@ -201,7 +202,9 @@ class GANTrainer:
         g = _unwrap(self.generator)
         if getattr(g, "noise_dimensions", 0) and not getattr(g, "noise_on_device", False):
             return False        # host RNG draws inside forward()
-        if self.loss_type_gan not in ("ModifiedMinMax", "Wasserstein") or not (self._train_d and self._train_g):
+        if self.loss_type_gan not in ("ModifiedMinMax", "Wasserstein"):
+            return False
+        if not self._always_eval and not (self._train_d and self._train_g):
             return False
         if type(self.g_opt).__name__ != "FusedAdam" or type(self.d_opt).__name__ != "FusedAdam":
             return False
@@ -211,8 +214,8 @@ class GANTrainer:
     def _graph_step(self, inputs, outputs_real, masks, labels, eta):
         from ..runtime import StatsPool as _SP
         s = self.step_count
-        train_g = (s < self.warmup) or (s % self.freq_g == 0)
-        train_d = (s >= self.warmup) and (s % self.freq_d == 0)
+        train_g, train_d = self._step_flags()
+        eval_d = train_d or self._always_eval      # the 3-D loop evaluates both losses every iteration (train_gan3d.py:250-360)
         # everything the capture bakes into launch arguments is part of the key: a changed loss weight, criterion or
         # optimiser hyper-parameter captures a new graph instead of silently replaying the old numbers
         def _opt_key(o):
@@ -235,10 +238,10 @@ class GANTrainer:
         # gradient penalty draws eta: deeplab_gan.py:99); the swap exchanges the two label tensors -- no branch in the graph
         n = outputs_real.shape[0]
         lab = None
-        if train_d and self.loss_type_gan == "ModifiedMinMax":
+        if eval_d and self.loss_type_gan == "ModifiedMinMax":
             lf, lr_, swap = labels if labels is not None else self.criterion_gan.draw_labels()
             lab = (lr_, lf) if swap else (lf, lr_)
-        if train_d and self.loss_type_gan == "Wasserstein" and eta is None:
+        if eval_d and self.loss_type_gan == "Wasserstein" and eta is None:
             eta = torch.distributions.uniform.Uniform(0., 1.).rsample((n, 1, 1, 1))
         dev = inputs.device
         if e is None:
@@ -318,11 +321,14 @@ class GANTrainer:
         self._graphs[key] = e
         g.replay()                      # capture records, it does not execute
 
+    def _step_flags(self):
+        """(train generator, train discriminator) of the current loop step (train_gan.py:247-248)."""
+        s = self.step_count
+        return (s < self.warmup) or (s % self.freq_g == 0), (s >= self.warmup) and (s % self.freq_d == 0)
+
     def _eager_step(self, inputs, outputs_real, masks=None, labels=None, eta=None):
         StatsPool.reset_all()   # one fill clears every statistic accumulator of the previous step
-        s = self.step_count
-        train_generator = (s < self.warmup) or (s % self.freq_g == 0)            # train_gan.py:247
-        train_discriminator = (s >= self.warmup) and (s % self.freq_d == 0)      # train_gan.py:248
+        train_generator, train_discriminator = self._step_flags()
         d_loss = g_loss = None
         g = _unwrap(self.generator)
         self._want_g_ahead = (self._g_ahead_ok and train_discriminator and train_generator and inputs.is_cuda

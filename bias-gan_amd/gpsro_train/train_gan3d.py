@@ -23,6 +23,7 @@ class GANTrainer3d(GANTrainer):
         self.d_loss_scale = self.w_gan
         self.d_acc_avg = 0.0
         self._batched_d = False     # the 3-D layers' pixel counts rarely split into whole 128-pixel tiles per half
+        self._always_eval = True    # both losses every iteration; the schedule's flags gate the two updates
 
     def update_flags(self):
         s, sch = self.step_count, self.schedule
@@ -40,19 +41,34 @@ class GANTrainer3d(GANTrainer):
             return True, True
         return True, True
 
-    def step(self, inputs, outputs_real, masks=None, labels=None, eta=None, comm=None):
+    def _step_flags(self):
+        return self.update_flags()
+
+    def _eager_step(self, inputs, outputs_real, masks=None, labels=None, eta=None):
         StatsPool.reset_all()
         self._train_g, self._train_d = self.update_flags()
         self._want_g_ahead = False
         d_loss = self.d_step(inputs, outputs_real, labels, eta)
-        if self.loss_type_gan == "ModifiedMinMax":
-            # the accuracy steers the NEXT iteration's schedule: a host value, like the reference's metric_average
-            acc = self.last_d_acc
-            self.d_acc_avg = comm.metric_average(acc, "train_accuracy_discriminator", device=acc.device) if comm is not None \
-                else float(acc)
         g_loss = self.g_step(inputs, outputs_real, masks)
         self._finish_d()
         self.step_count += 1
+        return d_loss, g_loss
+
+    def step(self, inputs, outputs_real, masks=None, labels=None, eta=None, comm=None):
+        """One iteration of train_gan3d.py:250-360.  Where the step qualifies it is one captured hipGraph per flag
+        combination (GANTrainer._graph_step): at the 45x19x37 GPS-RO grid the ~2 700 launches of 10-30 us are bound by the
+        host, not by the GPU."""
+        self._train_g, self._train_d = self.update_flags()
+        if self._graph_ok(inputs, outputs_real, masks):
+            d_loss, g_loss = self._graph_step(inputs, outputs_real, masks, labels, eta)
+        else:
+            d_loss, g_loss = self._eager_step(inputs, outputs_real, masks, labels, eta)
+        if self.loss_type_gan == "ModifiedMinMax":
+            # the accuracy steers the NEXT iteration's schedule: a host value, like the reference's metric_average (read
+            # after the iteration has been enqueued: it is only needed by the next update_flags())
+            acc = self.last_d_acc
+            self.d_acc_avg = comm.metric_average(acc, "train_accuracy_discriminator", device=acc.device) if comm is not None \
+                else float(acc)
         return d_loss, g_loss
 
 

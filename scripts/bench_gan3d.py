@@ -20,16 +20,16 @@ for (n, d, h, w) in ((16, 45, 19, 37), (4, 64, 96, 96)):
                       ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5), losses.GANLoss("ModifiedMinMax", n, dev),
                       losses.L1Loss())
     x = torch.randn(n, 1, d, h, w, device=dev); y = x + 0.1 * torch.randn_like(x)
-    for _ in range(2):
+    for _ in range(4):        # two eager steps, the capture, one replay
         tr.step(x, y)
     torch.cuda.synchronize()
-    steps = 5
+    steps = 10
     t0 = time.perf_counter()
     for _ in range(steps):
         dl, gl = tr.step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(f"volume {d}x{h}x{w}, batch {n}: {1e3 * dt:.1f} ms/step, {n / dt:.1f} samples/s  (d_loss {float(dl):.3f}, g_loss {float(gl):.3f})", flush=True)
+    print(f"[step graph {os.environ.get('BGAMD_STEP_GRAPH', 'auto')}: {len(getattr(tr, '_graphs', {}))} captured] volume {d}x{h}x{w}, batch {n}: {1e3 * dt:.1f} ms/step, {n / dt:.1f} samples/s  (d_loss {float(dl):.3f}, g_loss {float(gl):.3f})", flush=True)
     L.PROFILE = []
     tr.step(x, y)
     torch.cuda.synchronize()

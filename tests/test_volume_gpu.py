@@ -356,3 +356,44 @@ def test_train_gan3d_command_line():
         "--local_batch_size 2 --max_steps 2 --noise_dimensions 1".split()))
     assert tr.step_count == 2
     assert all(torch.isfinite(p).all() for p in tr.generator.parameters())
+
+
+@pytest.mark.parametrize("schedule", [{"type": "static", "update_frequency_generator": 1, "update_frequency_discriminator": 2},
+                                      {"type": "adaptive", "acc_min": 0.3, "acc_max": 0.9}])
+def test_trainer3d_whole_step_graph_matches_eager(monkeypatch, schedule):
+    """GANTrainer3d.step captured into one hipGraph per (train G, train D) flag combination and replayed (round 3: the
+    3-D loop at the GPS-RO grid is bound by its ~2 700 launches), against the eager schedule on the same seeds.  With the
+    learning rate at 0 every iteration's losses depend on that iteration's inputs and labels only and must agree to
+    rounding; the flags (static: D every second iteration; adaptive: from the previous iteration's critic accuracy, read
+    back after the replay) and the host-side counters must follow the eager run's."""
+    from bias_gan_amd.gpsro_train.train_gan3d import GANTrainer3d
+    from bias_gan_amd.utils import losses
+    from bias_gan_amd.utils import parsing_helpers as ph
+    n, c, d, h, w = 2, 1, 16, 24, 24
+
+    def run(flag):
+        monkeypatch.setenv("BGAMD_STEP_GRAPH", flag)
+        G = g3.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm3d, compute_dtype=F32)
+        D = g3.Discriminator(c, normalizer=nn.BatchNorm3d, compute_dtype=F32)
+        G.load_state_dict(o3.fill_state(o3.generator3d_spec(c, c, 0, "batch"), 41))
+        D.load_state_dict(o3.fill_state(o3.discriminator3d_spec(c, "batch"), 42))
+        G.to(DEV).train(), D.to(DEV).train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        tr = GANTrainer3d(G, D, ph.get_optimizer(G.parameters(), "Adam", 0.0, 1e-8, 0.0), ph.get_optimizer(D.parameters(), "Adam", 0.0, 1e-8, 0.0),
+                          crit, losses.L1Loss(), loss_weight_gan=0.5, relative_update_schedule=schedule)
+        out = []
+        for s_ in range(8):
+            torch.manual_seed(500 + s_)
+            x, y = (t.to(DEV) for t in o3.synthetic_volumes(n, c, d, h, w, 900 + s_))
+            d_loss, g_loss = tr.step(x, y)
+            out.append((float(d_loss), float(g_loss), tr._train_g, tr._train_d, round(tr.d_acc_avg, 6)))
+        torch.cuda.synchronize()
+        return out, len(getattr(tr, "_graphs", {})), (tr.g_opt._t, tr.d_opt._t, tr.step_count)
+
+    (e, ge, ce), (g, gg, cg) = run("0"), run("1")
+    assert ge == 0 and gg >= 1
+    assert ce == cg, (ce, cg)
+    for i, (a, b) in enumerate(zip(e, g)):
+        print(f"step {i}: eager d {a[0]:.6f} g {a[1]:.6f} flags {a[2:4]} acc {a[4]} | graph d {b[0]:.6f} g {b[1]:.6f} flags {b[2:4]} acc {b[4]}")
+        assert a[2:] == b[2:], (i, a, b)
+        assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]) + 1e-6, (i, a, b)
