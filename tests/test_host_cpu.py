@@ -156,8 +156,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_world_size_2_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -167,10 +168,11 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    tot = world * (world + 1) / 2.0      # sum over ranks of (rank + 1)
     for rank, s, a, fsum, f2, t in res:
-        assert s == 3.0 and a == 1.5
-        assert fsum == float(np.arange(1000).sum() * 3)
-        assert f2 == [3.0] * 7
+        assert s == tot and a == tot / world
+        assert fsum == float(np.arange(1000).sum() * tot)
+        assert f2 == [tot] * 7
         assert t == [0.0, 0.0, 0.0]
 
 
