@@ -18,7 +18,13 @@ timeout -k 10 400 python bench.py --loss wgan-gp --steps 10 --warmup 3 --no-cpu-
 python -c "import json;d=json.load(open('$O/bench_wgan_gp.json'));print('wgan-gp',d['value'],d['ms_per_step'],d['roofline']['step_conv_stack_frac'])"
 timeout -k 10 400 python bench.py --height 256 --width 256 --steps 30 --warmup 6 --no-cpu-baseline --no-kernel-profile > $O/bench_c2.json 2> $O/bench_c2.err || { tail -20 $O/bench_c2.err; exit 1; }
 python -c "import json;d=json.load(open('$O/bench_c2.json'));print('c2',d['value'],d['ms_per_step'],d.get('host_ms_per_step'))"
+# c5 (2304x1536x32, batch 4): bf16 and fp8 operands in the same call, and the rocprofv3 kernel statistics of the fp8 command
+timeout -k 10 500 python bench.py --height 2304 --width 1536 --channels 32 --batch 4 --steps 6 --warmup 2 --no-cpu-baseline --no-host-floor > $O/bench_c5_bf16.json 2> $O/bench_c5_bf16.err || { tail -20 $O/bench_c5_bf16.err; exit 1; }
+timeout -k 10 500 python bench.py --height 2304 --width 1536 --channels 32 --batch 4 --steps 6 --warmup 2 --no-cpu-baseline --no-host-floor --dtype fp8 > $O/bench_c5_fp8.json 2> $O/bench_c5_fp8.err || { tail -20 $O/bench_c5_fp8.err; exit 1; }
+python -c "import json;a=json.load(open('$O/bench_c5_bf16.json'));b=json.load(open('$O/bench_c5_fp8.json'));print('c5 bf16',a['value'],a['ms_per_step'],'fp8',b['value'],b['ms_per_step'],b['roofline']['kernel'],b['roofline']['frac'])"
 export TMPDIR=/tmp; cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o bench -- python3 $R/bench.py --height 2304 --width 1536 --channels 32 --batch 4 --dtype fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_c5.json 2> $O/prof_c5.err || { tail -5 $O/prof_c5.err; exit 1; }
+echo c5 fp8 kernel-trace done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_bench.json 2> $O/prof_bench.err || { tail -5 $O/prof_bench.err; exit 1; }
 echo kernel-trace done
 BGAMD_NO_WGRAD_STREAM=1 BGAMD_NO_SIDE_STREAM=1 BGAMD_NO_G_PREFETCH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_single.json 2> $O/prof_single.err || { tail -5 $O/prof_single.err; exit 1; }
@@ -36,5 +42,6 @@ python scripts/pmc_summary.py $F $W $O/pmc_hbm_traffic.json | head -12
 python scripts/pmc_sq_summary.py $S $O/pmc_sq.json
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cp $(find $O/prof_single -name "*kernel_stats.csv" | head -1) $O/kernel_stats_single_stream.csv
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/prof $O/prof_single
+cp $(find $O/prof_c5 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c5_fp8.csv
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/prof $O/prof_single $O/prof_c5
 ls -la $O
