@@ -288,7 +288,8 @@ def main():
         devs = [None] * world
         dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} ({torch.cuda.get_device_name()})")
         if rank == 0:
-            print(f"[bench] torch.distributed backend {dist.get_backend()} (RCCL on ROCm), world size {dist.get_world_size()}: "
+            print(f"[bench] torch.distributed backend {dist.get_backend()}" + (" (= RCCL on ROCm)" if dist.get_backend() == "nccl" else " (rehearsal)")
+                  + f", world size {dist.get_world_size()}: "
                   + "; ".join(devs), file=sys.stderr, flush=True)
 
     batches = [synthetic_batch(n, c, h, w, seed + 1000 * i, device) for i in range(2)]
