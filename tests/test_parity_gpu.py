@@ -452,13 +452,13 @@ def test_discriminator_vs_reference_golden(golden_dir, tag, dtype):
         assert e <= 5e-4
         assert rel_err(pred.detach().cpu(), z["pred"]) <= 5e-4
     else:
-        assert e <= 5e-1
+        assert e <= 4e-1        # 2 x measured over the three goldens (3.8e-2, 1.97e-1, 1.23e-1)
         P = orc.fill_state(spec, m["seed"])
         with torch.no_grad():
             emu, _ = orc.discriminator(P, x, orc.NormCtx(m["norm"], True, bf16=True))
         e2 = rel_err(logits.detach().cpu(), emu.numpy())
         print(f"discriminator {tag} bf16: logits vs bf16-rounding oracle max-rel {e2:.2e}")
-        assert e2 <= 5e-1
+        assert e2 <= 1.8e-1     # 2 x measured (1.0e-2, 6.7e-2, 8.8e-2)
     tgt = torch.linspace(0.1, 0.9, m["n"]).reshape(-1, 1).to(DEV)
     loss = ops.BCEWithLogitsFn.apply(logits, tgt)
     loss.backward()
@@ -471,7 +471,10 @@ def test_discriminator_vs_reference_golden(golden_dir, tag, dtype):
             got = cs(p.grad)
             assert abs(got[2] - ref[k][2]) <= 6e-2 * ref[k][2] + 1e-12, (k, got, ref[k])
     else:
-        assert np.isfinite(er)
+        # the input gradient after 70 bf16 layers on 4 x 4 .. 3 x 4 maps is half decorrelated from the fp32 one (rms-rel
+        # 0.50 .. 0.58 measured; per Block the backward is 3-5e-2, test_blocks_teacher_forced_bf16_backward): bounded at
+        # 2 x measured, which still tells it from a wrong scale or a dropped layer
+        assert er <= 1.16 and 0.25 <= float(xg.grad.float().pow(2).sum().sqrt() / torch.as_tensor(z["dx"]).float().pow(2).sum().sqrt()) <= 4.0
 
 
 def test_gan_losses_vs_reference_golden(golden_dir):
@@ -556,9 +559,9 @@ def test_one_iteration_bf16_close_to_fp32(golden_dir):
     z, m = gz(golden_dir, "trajectory_mmm.npz")
     _, _, d_loss, g_loss = _one_iteration(m, BF16, m["mode"])
     print(f"bf16 iteration: d_loss {d_loss} (ref {z['d_loss'][0]}), g_loss {g_loss} (ref {z['g_loss'][0]})")
-    # 140 layers of bf16 storage on a randomly filled net (see module docstring): 30 %
-    assert abs(d_loss - z["d_loss"][0]) <= 3e-1 * abs(z["d_loss"][0])
-    assert np.isfinite(g_loss)
+    # 140 layers of bf16 storage on a randomly filled net (see module docstring); 2 x measured (d_loss 3.0e-2, g_loss 1.8e-2)
+    assert abs(d_loss - z["d_loss"][0]) <= 6e-2 * abs(z["d_loss"][0])
+    assert abs(g_loss - z["g_loss"][0]) <= 3.6e-2 * abs(z["g_loss"][0])
 
 
 def test_generator_vs_oracle_128(golden_dir):
