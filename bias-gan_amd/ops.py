@@ -410,9 +410,10 @@ class Conv2dFn(torch.autograd.Function):
             # arena's e4m3 weights; bf16 output and statistics as below.  Until the sites have been calibrated (the first
             # training step) the GEMM stays on bf16 and the quantiser only records the input's max |value|.
             ep, ap = arena.site_ptrs(wslot, grad=False)
-            if xq is None or xq[1] != ep or not arena.sites_ready:
+            ready = arena.site_ready(wslot, grad=False)
+            if xq is None or xq[1] != ep or not ready:
                 xq = (fp8_quant(x, L.FP8_E4M3, ep, ap), ep)
-            use8 = arena.sites_ready
+            use8 = ready
         if use8:
             xq = xq[0]
             d8 = L.ConvDesc(L.BF16, n, h, w, xq.shape[3], ho, wo, kp, kh, kw, stride, pad, dil, ld_of(xq), ld_of(y))
@@ -461,9 +462,10 @@ class Conv2dFn(torch.autograd.Function):
                     and fp8_layer_ok(arena, wslot, kh, kw, grad=True, prequantised=gq is not None))
             if use8:
                 ep, ap = arena.site_ptrs(wslot, grad=True)
-                if gq is None or gq[1] != ep or not arena.sites_ready:
+                ready = arena.site_ready(wslot, grad=True)
+                if gq is None or gq[1] != ep or not ready:
                     gq = (fp8_quant(g, L.FP8_E5M2, ep, ap), ep)
-                use8 = arena.sites_ready
+                use8 = ready
             if use8:
                 gq = gq[0]
                 d8 = L.ConvDesc(L.BF16, n, h, w, cin, ho, wo, gq.shape[3], kh, kw, stride, pad, dil, ld_of(dx), ld_of(gq))

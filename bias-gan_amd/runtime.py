@@ -201,7 +201,11 @@ class Arena:
         self.site_exp = torch.zeros(2 * n, dtype=torch.int32, device=dev)
         self.site_amax = torch.zeros(2 * n, dtype=torch.int32, device=dev)
         self.site_fmt = torch.tensor([L.FP8_E4M3, L.FP8_E5M2] * n, dtype=torch.int32, device=dev)
-        self.sites_ready = False       # the first step calibrates: bf16 GEMMs, the quantiser only records max |value|
+        # a site is READY once a roll has turned a recorded maximum into its exponent; until then its GEMM runs on the bf16
+        # operand and the quantiser only records max |value| (the first step of a run, or the first time a schedule -- warm-up,
+        # update frequencies -- reaches a layer's backward pass).  Tracked on the host: it knows which sites it launched.
+        self._site_seen, self._site_ready = set(), set()
+        self.sites_ready = False       # any roll so far (informational)
         self.n_fp8_layers = len(layers)
 
     def roll_fp8(self):
@@ -209,7 +213,15 @@ class Arena:
         if self.fp8 and self.n_fp8_layers:
             L.call("bg_fp8_roll", self.site_exp.data_ptr(), self.site_amax.data_ptr(), self.site_fmt.data_ptr(),
                    2 * self.n_fp8_layers, 1)
+            self._site_ready |= self._site_seen
+            self._site_seen.clear()
             self.sites_ready = True
+
+    def site_ready(self, s: ParamSlot, grad: bool) -> bool:
+        """Has this site's exponent been derived from data it saw?  Also marks the site as seen in this step."""
+        i = 2 * s.f8 + (1 if grad else 0)
+        self._site_seen.add(i)
+        return i in self._site_ready
 
     def weight8_ptr(self, s: ParamSlot) -> int:
         return self.wk8.data_ptr() + s.k8_off

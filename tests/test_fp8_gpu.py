@@ -410,3 +410,31 @@ def test_fp8_whole_step_graph(monkeypatch):
     for i, (a, b) in enumerate(zip(e, g)):
         print(f"step {i}: eager d {a[0]:.6f} g {a[1]:.6f} | graph d {b[0]:.6f} g {b[1]:.6f}")
         assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]), (i, a, b)
+
+
+def test_fp8_sites_become_ready_one_by_one(monkeypatch):
+    """A quantisation site runs its GEMM on fp8 operands only after a roll has given it an exponent from data it saw
+    (runtime.Arena.site_ready): forward-only passes calibrate the forward sites; the first backward pass after that still
+    runs its data gradients on bf16 operands (an uncalibrated e5m2 site with exponent 0 would flush 1e-6-sized
+    gradients to zero), the next one on fp8."""
+    monkeypatch.setattr(ops, "_FP8_MIN_WORK", 0)
+    c, h, w, n = 4, 64, 64, 2
+    G, _, _, _ = build(c, h, w, FP8)
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 1000))
+
+    def run(backward):
+        L.PROFILE = []
+        out = G(x)
+        if backward:
+            losses.L1Loss()(out, y).backward()
+        torch.cuda.synchronize()
+        names = [p[0] for p in L.PROFILE]
+        L.PROFILE = None
+        G.arena().roll_fp8()
+        return names.count("bg_conv2d_fwd_fp8"), names.count("bg_conv2d_bwd_data_fp8"), names.count("bg_conv2d_bwd_data")
+
+    a = run(False)      # calibration of the forward sites
+    b = run(True)       # forward on fp8; backward sites seen for the first time: bf16 data gradients
+    c_ = run(True)      # everything on fp8
+    print(a, b, c_)
+    assert a[0] == 0 and b[0] > 50 and b[1] == 0 and b[2] > 50 and c_[0] == b[0] and c_[1] > 50 and c_[2] < b[2]
