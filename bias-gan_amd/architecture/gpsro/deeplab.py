@@ -83,7 +83,10 @@ class Conv2d(BGModule):
         if self.groups > 1:
             return ops.DwConv3x3Fn.apply(x, self.weight, a, ws, self.stride[0], self.dilation[0])
         if self.bias is None or not with_bias:
-            return ops.Conv2dFn.apply(x, self.weight, None, a, ws, None, self.stride[0], self.padding[0], self.dilation[0], stats)
+            y = ops.Conv2dFn.apply(x, self.weight, None, a, ws, None, self.stride[0], self.padding[0], self.dilation[0], stats)
+            if getattr(a, "fp8", False):
+                ops.fp8_tag_output(y, a, ws, *self.kernel_size)
+            return y
         return ops.Conv2dFn.apply(x, self.weight, self.bias, a, ws, a.by_param[id(self.bias)], self.stride[0], self.padding[0],
                                   self.dilation[0], stats)
 

@@ -579,14 +579,21 @@ struct EwBwdParams {
     float* dgamma; float* dbeta;
     int train; int groups;
     int gx, gy;
+    // Q8 (fp8 operand path): dx is ALSO written as e5m2 bytes -- the data-gradient GEMM of the pointwise convolution that
+    // produced x reads it as its operand -- q = e5m2(clamp(dx_as_stored * 2^(*q_exp))), C rounded up to 16 with zero lanes,
+    // and *q_amax = max(*q_amax, max |dx|) for the next step's exponent (bg_quant_fp8's contract, one pass saved)
+    unsigned char* dxq; int lddxq; const int* q_exp; unsigned* q_amax;
 };
 
 // SIGN: where the activation's branch comes from (0 no activation, 1 the stored output y, 2 recomputed from
 // x*scale+shift); DRES: also write the residual branch's gradient; USEB: training-mode statistics terms (needs x).
 // Compile-time so that the per-element code carries no selects on run-time flags (see norm_act_fwd_kernel).
-template <typename T, int SIGN, bool DRES, bool USEB>
+template <typename T, int SIGN, bool DRES, bool USEB, bool Q8 = false>
 __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) {
     constexpr int VEC = Elem<T>::VEC;
+    static_assert(!Q8 || sizeof(T) == 2, "the fp8 copy is taken from a bf16 gradient");
+    __shared__ unsigned q_blk_amax;
+    if (Q8 && threadIdx.x == 0) q_blk_amax = 0u;   // published by the __syncthreads() after the coefficient table
     const int ly = (int)threadIdx.x / P.tx;
     const int lx = (int)threadIdx.x - ly * P.tx;
     const int ty = P.ty;
@@ -661,7 +668,12 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
     const long long s_dy = (long long)ty * P.lddy, s_y = (long long)ty * P.ldy, s_x = (long long)ty * P.ldx;
     const long long s_dx = (long long)ty * P.lddx, s_dr = (long long)ty * P.lddres;
     const float slope = act_slope(P.act);
-    auto row = [&](const Chunk<T>& vg, const Chunk<T>& vy, const Chunk<T>& vx, T* o_res, T* o_dx) {
+    const float q_scale = Q8 ? ldexpf(1.f, *P.q_exp) : 0.f;
+    float q_mx = 0.f;
+    unsigned char* dxq = Q8 ? P.dxq + row0 * P.lddxq + c : nullptr;
+    const long long s_dq = (long long)ty * P.lddxq;
+    const bool q_pad = Q8 && c + VEC == P.C && (P.C & 8);   // this thread also owns the 8 zero lanes that round C up to 16
+    auto row = [&](const Chunk<T>& vg, const Chunk<T>& vy, const Chunk<T>& vx, T* o_res, T* o_dx, unsigned char* o_q) {
         Chunk<T> vo;
         float gg[VEC];
 #pragma unroll
@@ -683,6 +695,25 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
                 vo.set(e, d);
             }
             vo.store(o_dx);
+            if constexpr (Q8) {
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = vo.get(e);                       // the gradient as stored (bf16)
+                    q_mx = fmaxf(q_mx, fabsf(v[e]));
+                    v[e] = fminf(fmaxf(v[e] * q_scale, -57344.f), 57344.f);
+                }
+                u32x2 qv;
+                int w0 = 0, w1 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], w1, true);
+                qv[0] = (unsigned)w0; qv[1] = (unsigned)w1;
+                *reinterpret_cast<u32x2*>(o_q) = qv;
+                if (q_pad) *reinterpret_cast<u32x2*>(o_q + 8) = u32x2{0u, 0u};
+            }
         }
     };
     auto load = [&](Chunk<T>* vg, Chunk<T>* vy, Chunk<T>* vx) {
@@ -714,9 +745,10 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
         have = r + step - ty < r1;
         if (have) load(vg, vy, vx);
 #pragma unroll
-        for (int u = 0; u < EW_U; ++u) row(cg[u], cy[u], cx[u], dres + u * s_dr, dx + u * s_dx);
+        for (int u = 0; u < EW_U; ++u) row(cg[u], cy[u], cx[u], dres + u * s_dr, dx + u * s_dx, Q8 ? dxq + u * s_dq : nullptr);
         if (DRES) dres += EW_U * s_dr;
         if (dx) dx += EW_U * s_dx;
+        if (Q8) dxq += EW_U * s_dq;
     }
     for (; r < r1; r += ty) {
         Chunk<T> v1, v2, v3;
@@ -724,15 +756,28 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
         dy += s_dy;
         if (SIGN == 1) { v2.load(y); y += s_y; }
         if (LDX) { v3.load(x); x += s_x; }
-        row(v1, v2, v3, dres, dx);
+        row(v1, v2, v3, dres, dx, dxq);
         if (DRES) dres += s_dr;
         if (dx) dx += s_dx;
+        if (Q8) dxq += s_dq;
+    }
+    if constexpr (Q8) {   // one atomic per workgroup (|v| as float bits orders like the unsigned integer)
+        if (q_mx > 0.f) atomicMax(&q_blk_amax, __float_as_uint(q_mx));
+        __syncthreads();    // threads that left at `c >= P.C` are whole inactive lanes of waves that still arrive here
+        if (threadIdx.x == 0 && q_blk_amax) atomicMax(P.q_amax, q_blk_amax);
     }
 }
 
 template <typename T, int SIGN>
 void launch_bwd_apply_s(const EwBwdParams& P, const dim3 grid, const dim3 block, bool useB, hipStream_t st) {
     const size_t lds = (size_t)5 * P.tx * Elem<T>::VEC * sizeof(float);
+    if constexpr (sizeof(T) == 2 && SIGN != 0) {
+        if (P.dxq) {   // (the entry point admits the fp8 copy only with the training-mode terms)
+            if (P.dres) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, true, true, true>), grid, block, lds, st, P);
+            else hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, false, true, true>), grid, block, lds, st, P);
+            return;
+        }
+    }
     if (P.dres) {
         if (useB) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, true, true>), grid, block, lds, st, P);
         else hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, true, false>), grid, block, lds, st, P);
@@ -971,6 +1016,14 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
     return BG_OK;
 }
 
+namespace {
+int bwd_apply_stats_impl(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x, int32_t ldx,
+                         const double* s1, const double* s2, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
+                         int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act, void* dxq, int32_t lddxq,
+                         const int32_t* q_exp, uint32_t* q_amax, void* stream);
+}
+
 extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
                                            const void* x, int32_t ldx, const double* s1, const double* s2,
                                            const float* gamma, const float* beta, const float* mean,
@@ -978,6 +1031,32 @@ extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_
                                            int32_t lddx, void* dres,
                                            int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act,
                                            void* stream) {
+    return bwd_apply_stats_impl(dtype, dy, lddy, y, ldy, x, ldx, s1, s2, gamma, beta, mean, rstd, train, dgamma, dbeta, dx, lddx,
+                                dres, lddres, rows, C, groups, act, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int bg_norm_act_bwd_apply_stats_q8(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
+                                              const void* x, int32_t ldx, const double* s1, const double* s2,
+                                              const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                              int32_t train, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
+                                              int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act, void* dxq,
+                                              int32_t lddxq, const int32_t* q_exp, uint32_t* q_amax, void* stream) {
+    BG_CHECK_ARG(dtype == BG_BF16 && train && act && dx && dxq && q_exp && q_amax && aligned16(dxq) && lddxq % 16 == 0 &&
+                     lddxq >= (C + 15) / 16 * 16,
+                 "bg_norm_act_bwd_apply_stats_q8: bf16, training mode, an activation, dx and a 16-byte-aligned fp8 buffer of "
+                 "pixel stride >= C rounded up to 16");
+    return bwd_apply_stats_impl(dtype, dy, lddy, y, ldy, x, ldx, s1, s2, gamma, beta, mean, rstd, train, dgamma, dbeta, dx, lddx,
+                                dres, lddres, rows, C, groups, act, dxq, lddxq, q_exp, q_amax, stream);
+}
+
+namespace {
+int bwd_apply_stats_impl(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
+                         const void* x, int32_t ldx, const double* s1, const double* s2,
+                         const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx,
+                         int32_t lddx, void* dres,
+                         int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act, void* dxq, int32_t lddxq,
+                         const int32_t* q_exp, uint32_t* q_amax, void* stream) {
     int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_apply_stats");
     if (rc) return rc;
     CHECK_LD(lddy, "bg_norm_act_bwd_apply_stats");
@@ -1004,7 +1083,9 @@ extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_
     EwBwdParams P{dy, lddy, y, ldy, x, ldx, nullptr, nullptr, nullptr, dx, lddx, dres, lddres, C, rows / groups,
                   t.rows_per_block, act, t.tx, t.ty, s1, s2, gamma, beta, mean, rstd, dgamma, dbeta, train, groups};
     P.gx = t.gx; P.gy = t.gy;
+    P.dxq = (unsigned char*)dxq; P.lddxq = lddxq; P.q_exp = q_exp; P.q_amax = q_amax;
     launch_bwd_apply(dtype, P, t, groups, (hipStream_t)stream);
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel(stats)");
     return BG_OK;
 }
+}  // namespace

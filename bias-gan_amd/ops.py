@@ -386,6 +386,37 @@ def fp8_amax_only(t: torch.Tensor, fmt: int, exp_ptr: int, amax_ptr: int):
     fp8_quant(t, fmt, exp_ptr, amax_ptr)
 
 
+def fp8_tag_output(y: torch.Tensor, arena: Arena, wslot: ParamSlot, kh, kw):
+    """Mark a dense convolution's output with the quantisation site of its OUTPUT GRADIENT: the BatchNorm backward that
+    later produces that gradient writes the e5m2 copy itself (bg_norm_act_bwd_apply_stats_q8) instead of leaving a
+    quantisation pass to the convolution's backward."""
+    if fp8_layer_ok(arena, wslot, kh, kw, grad=True, prequantised=True) and wslot.phys_shape[3] >= 64:
+        y._bg_dy_site = (arena, wslot)
+
+
+def _apply_stats_maybe_q8(q_site, dx, args, n, h, w, c):
+    """bg_norm_act_bwd_apply_stats, or its _q8 form when the consumer of dx is an fp8 data-gradient GEMM whose site is
+    calibrated: dx then carries its e5m2 copy (dx._bg_fp8)."""
+    if q_site is not None and dx is not None and dx.dtype == torch.bfloat16:
+        qa, qw = q_site
+        ep, ap = qa.site_ptrs(qw, grad=True)
+        if qa.site_ready(qw, grad=True):
+            cq = (c + 15) // 16 * 16
+            ldq = (cq + 63) // 64 * 64
+            dxq = torch.empty((n, h, w, ldq), dtype=torch.uint8, device=dx.device)
+            L.call("bg_norm_act_bwd_apply_stats_q8", *args, dxq.data_ptr(), ldq, ep, ap)
+            qa.site_seen(qw, grad=True)
+            dx._bg_fp8 = (dxq[..., :cq], ep)
+            return
+        # not calibrated yet: the plain kernel, then one pass that only records the site's max |dx| (the consuming
+        # convolution would not take it for layers below the stand-alone threshold)
+        L.call("bg_norm_act_bwd_apply_stats", *args)
+        fp8_amax_only(dx, L.FP8_E5M2, ep, ap)
+        qa.site_seen(qw, grad=True)
+        return
+    L.call("bg_norm_act_bwd_apply_stats", *args)
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d(groups=1) as implicit GEMM (bg_conv2d_*)."""
 
@@ -413,6 +444,7 @@ class Conv2dFn(torch.autograd.Function):
             ready = arena.site_ready(wslot, grad=False)
             if xq is None or xq[1] != ep or not ready:
                 xq = (fp8_quant(x, L.FP8_E4M3, ep, ap), ep)
+                arena.site_seen(wslot, grad=False)
             use8 = ready
         if use8:
             xq = xq[0]
@@ -465,6 +497,7 @@ class Conv2dFn(torch.autograd.Function):
                 ready = arena.site_ready(wslot, grad=True)
                 if gq is None or gq[1] != ep or not ready:
                     gq = (fp8_quant(g, L.FP8_E5M2, ep, ap), ep)
+                    arena.site_seen(wslot, grad=True)
                 use8 = ready
             if use8:
                 gq = gq[0]
@@ -694,6 +727,7 @@ class NormActFn(torch.autograd.Function):
         """bn_groups: 'batch' statistics are taken separately over that many equal sub-batches (see
         batch_groups()).  pre_stats: fp64 [2, groups, C] sums already produced by the convolution's epilogue
         (bg_conv2d_fwd_stats); skips the separate statistics pass."""
+        ctx.q_site = getattr(x, "_bg_dy_site", None)
         x = nhwc(x)
         n, h, w, c = x.shape
         dev, dt = x.device, L.dt(x.dtype)
@@ -769,10 +803,11 @@ class NormActFn(torch.autograd.Function):
                 arena.ensure_grad(bslot)
                 dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
             # finalize (coefficients, dgamma/dbeta) is folded into the apply kernel
-            L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
-                   s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
-                   1 if batch_stats else 0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
-                   0 if dres is None else ld_of(dres), rows, c, groups, act)
+            args = (dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
+                    s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
+                    1 if batch_stats else 0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
+                    0 if dres is None else ld_of(dres), rows, c, groups, act)
+            _apply_stats_maybe_q8(ctx.q_site if (batch_stats and act) else None, dx, args, *x.shape)
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
@@ -795,6 +830,7 @@ class NormActDwConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, dw_weight, arena: Arena, gslot, bslot, wslot: ParamSlot, rmean, rvar, act, eps,
                 momentum, pre_stats, bn_groups, dil):
+        ctx.q_site = getattr(x, "_bg_dy_site", None)
         x = nhwc(x)
         n, h, w, c = x.shape
         dev, dt = x.device, L.dt(x.dtype)
@@ -872,9 +908,10 @@ class NormActDwConvFn(torch.autograd.Function):
             arena.ensure_grad(bslot)
             dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
-        L.call("bg_norm_act_bwd_apply_stats", dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x),
-               s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx),
-               0 if dx is None else ld_of(dx), None, 0, rows, c, groups, act)
+        args = (dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x),
+                s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx),
+                0 if dx is None else ld_of(dx), None, 0, rows, c, groups, act)
+        _apply_stats_maybe_q8(ctx.q_site if act else None, dx, args, n, h, w, c)
         return (dx,) + (None,) * 15
 
 

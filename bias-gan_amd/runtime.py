@@ -218,10 +218,12 @@ class Arena:
             self.sites_ready = True
 
     def site_ready(self, s: ParamSlot, grad: bool) -> bool:
-        """Has this site's exponent been derived from data it saw?  Also marks the site as seen in this step."""
-        i = 2 * s.f8 + (1 if grad else 0)
-        self._site_seen.add(i)
-        return i in self._site_ready
+        """Has this site's exponent been derived from data it saw?"""
+        return 2 * s.f8 + (1 if grad else 0) in self._site_ready
+
+    def site_seen(self, s: ParamSlot, grad: bool):
+        """A launch that records this site's max |value| has been issued in this step (the next roll makes it ready)."""
+        self._site_seen.add(2 * s.f8 + (1 if grad else 0))
 
     def weight8_ptr(self, s: ParamSlot) -> int:
         return self.wk8.data_ptr() + s.k8_off

@@ -147,6 +147,15 @@ int bg_pack_conv_weights(int32_t dtype, const void* src, void* dst_krsc, void* d
  * bg_conv2d_bwd_data_fp8: dx (bf16) = conv_transpose(dyq, wtq); dy_fmt names dyq's format; d->Cout / d->ldy
  *   describe dyq, d->Cin / d->ldx the bf16 dx.
  * ------------------------------------------------------------------------- */
+/* bg_norm_act_bwd_apply_stats that ALSO writes dx as e5m2 bytes for the data-gradient GEMM of the convolution that
+ * produced x (bg_quant_fp8's contract with fmt = BG_FP8_E5M2 on the dx values as stored; dxq: [rows][lddxq] bytes, C
+ * rounded up to 16 with zero lanes; *q_amax updated): one quantisation pass saved per layer.  bf16, training mode,
+ * with an activation, dx required. */
+int bg_norm_act_bwd_apply_stats_q8(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
+                                   int32_t ldx, const double* s1, const double* s2, const float* gamma, const float* beta,
+                                   const float* mean, const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx,
+                                   int32_t lddx, void* dres, int32_t lddres, int64_t rows, int32_t C, int32_t groups,
+                                   int32_t act, void* dxq, int32_t lddxq, const int32_t* q_exp, uint32_t* q_amax, void* stream);
 int bg_quant_fp8(int32_t src_dtype, const void* x, int32_t ldx, int64_t rows, int32_t C, void* xq, int32_t ldq, int32_t Cq,
                  int32_t fmt, const int32_t* exp, uint32_t* amax, void* stream);
 int bg_fp8_roll(int32_t* exp, uint32_t* amax, const int32_t* fmt, int32_t n, int32_t margin, void* stream);

@@ -438,3 +438,88 @@ def test_fp8_sites_become_ready_one_by_one(monkeypatch):
     c_ = run(True)      # everything on fp8
     print(a, b, c_)
     assert a[0] == 0 and b[0] > 50 and b[1] == 0 and b[2] > 50 and c_[0] == b[0] and c_[1] > 50 and c_[2] < b[2]
+
+
+@pytest.mark.parametrize("c", [728, 64, 40])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_norm_bwd_apply_writes_the_e5m2_copy(c, with_res):
+    """bg_norm_act_bwd_apply_stats_q8: dx identical to bg_norm_act_bwd_apply_stats', its e5m2 copy BIT-EXACT against
+    torch's cast of the stored bf16 dx scaled by the site's exponent (pad lanes zero), the site's max |dx| recorded."""
+    n, h, w, groups, act = 2, 9, 11, 1, 1
+    rows = n * h * w
+    g_ = torch.Generator().manual_seed(c)
+    ld = up(c, 32)
+    dt = torch.bfloat16
+    x = (torch.randn(rows, ld, generator=g_) * 2 + 0.3).to(dt).to(DEV)
+    gy = (torch.randn(rows, ld, generator=g_) * 1e-3).to(dt).to(DEV)
+    y = (torch.randn(rows, ld, generator=g_)).to(dt).to(DEV) if with_res else None      # stored output: the activation's branch
+    gamma, beta = (torch.rand(c, generator=g_) + 0.5).to(DEV), torch.randn(c, generator=g_).to(DEV)
+    s, ss = torch.zeros(groups, c, dtype=torch.float64, device=DEV), torch.zeros(groups, c, dtype=torch.float64, device=DEV)
+    L.call("bg_norm_stats", L.BF16, x.data_ptr(), rows, c, ld, groups, s.data_ptr(), ss.data_ptr())
+    mean, rstd, scale, shift = (torch.zeros(groups, c, device=DEV) for _ in range(4))
+    L.call("bg_norm_finalize_affine", s.data_ptr(), ss.data_ptr(), rows // groups, groups, c, gamma.data_ptr(), beta.data_ptr(),
+           1e-5, 0.1, None, None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    s1, s2 = torch.zeros(groups, c, dtype=torch.float64, device=DEV), torch.zeros(groups, c, dtype=torch.float64, device=DEV)
+    L.call("bg_norm_act_bwd_reduce", L.BF16, gy.data_ptr(), ld, L.ptr(y), ld, x.data_ptr(), ld, mean.data_ptr(), rstd.data_ptr(),
+           gamma.data_ptr(), beta.data_ptr(), rows, c, groups, act, s1.data_ptr(), s2.data_ptr())
+    outs = []
+    cq, ldq = up(c, 16), up(up(c, 16), 64)
+    e_val = 12
+    for q8 in (False, True):
+        dx = torch.full((rows, ld), 5.0, dtype=dt, device=DEV)
+        dres = torch.full((rows, ld), 5.0, dtype=dt, device=DEV) if with_res else None
+        dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        args = [L.BF16, gy.data_ptr(), ld, L.ptr(y), ld, x.data_ptr(), ld, s1.data_ptr(), s2.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), dx.data_ptr(), ld, L.ptr(dres), ld, rows, c, groups, act]
+        if q8:
+            dxq = torch.full((rows, ldq), 0x55, dtype=torch.uint8, device=DEV)
+            ex = torch.tensor([e_val], dtype=torch.int32, device=DEV)
+            am = torch.zeros(1, dtype=torch.int32, device=DEV)
+            L.call("bg_norm_act_bwd_apply_stats_q8", *args, dxq.data_ptr(), ldq, ex.data_ptr(), am.data_ptr())
+        else:
+            L.call("bg_norm_act_bwd_apply_stats", *args)
+        torch.cuda.synchronize()
+        outs.append((dx.clone(), None if dres is None else dres.clone(), dg.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    if with_res:
+        assert torch.equal(outs[0][1], outs[1][1])
+    dxs = outs[1][0][:, :c]
+    ref = torch_quant(dxs.cpu(), e_val, L.FP8_E5M2)
+    got = dxq.cpu()
+    assert torch.equal(got[:, :c], ref), f"{(got[:, :c] != ref).sum().item()} bytes differ"
+    assert (got[:, c:cq] == 0).all() and (got[:, cq:] == 0x55).all()
+    assert am.view(torch.float32).item() == dxs.float().abs().max().item()
+    assert (outs[1][0][:, c:].float() == 5.0).all()
+
+
+def test_fp8_backward_uses_the_producer_written_copy(monkeypatch):
+    """With the sites calibrated, the BatchNorm backward writes the e5m2 copy of the gradient its pointwise convolution's
+    data-gradient GEMM reads (bg_norm_act_bwd_apply_stats_q8): those layers need no bg_quant_fp8 pass, including the
+    narrow ones the default layer rule would otherwise leave on bf16 operands."""
+    monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    c, h, w, n = 4, 64, 64, 2
+    G, D, _, _ = build(c, h, w, FP8)
+    tr, _ = trainer(G, D, n)
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 1000))
+    counts = []
+    for _ in range(3):
+        L.PROFILE = []
+        tr.step(x, y)
+        torch.cuda.synchronize()
+        names = [p[0] for p in L.PROFILE]
+        L.PROFILE = None
+        counts.append({k: names.count(k) for k in ("bg_norm_act_bwd_apply_stats_q8", "bg_norm_act_bwd_apply_stats", "bg_quant_fp8",
+                                                    "bg_conv2d_bwd_data_fp8", "bg_conv2d_bwd_data")})
+    print(counts)
+    assert counts[0]["bg_norm_act_bwd_apply_stats_q8"] == 0                      # calibration step
+    assert counts[2]["bg_norm_act_bwd_apply_stats_q8"] > 100 and counts[2]["bg_conv2d_bwd_data_fp8"] > 100
+    assert counts[2]["bg_quant_fp8"] < counts[0]["bg_quant_fp8"]
+    # every site the fused producer feeds was calibrated from data (gradients of 1e-3 .. 1e-7 need large exponents; an
+    # exponent left at 0 would flush them to zero in e5m2)
+    for net in (G, D):
+        a = net.arena()
+        ready_grad = sorted(i for i in a._site_ready if i & 1)
+        ex = a.site_exp.cpu()
+        assert len(ready_grad) > 50 and all(int(ex[i]) >= 5 for i in ready_grad), [(i, int(ex[i])) for i in ready_grad if int(ex[i]) < 5]
+    d_loss, g_loss = tr.step(x, y)
+    assert np.isfinite(float(d_loss)) and np.isfinite(float(g_loss))
