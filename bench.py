@@ -41,13 +41,13 @@ FWD_GMAC = {(1152, 768, 16): (313.9, 190.2), (256, 256, 16): (23.25, 14.09), (64
             (2304, 1536, 32): (1272.9, 776.9)}
 
 
-def w_alg_tflop(h, w, c, loss):
+def w_alg_tflop(h, w, c, loss, g_units=4):
     """4 G-units + 8 D-units per sample and step; the gradient penalty adds one D forward and one data-gradient-only D
     backward = 2 D-units (c4 = c3 + 2 D = 6.31 TFLOP)."""
     if (h, w, c) not in FWD_GMAC:
         return None
     g, d = FWD_GMAC[(h, w, c)]
-    return 2.0 * (4 * g + (10 if loss == "wgan-gp" else 8) * d) * 1e-3
+    return 2.0 * (g_units * g + (10 if loss == "wgan-gp" else 8) * d) * 1e-3
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (the block-scaled f8f6f4 MFMA forms; same table)
 PEAK_F32_TFLOPS = 157.3
@@ -74,6 +74,9 @@ def parse():
                          "ring: every step's batch comes from .npy files (HWC fp32, one sample per file, the CAM layout) "
                          "through the pinned-host -> HBM staging ring while the previous step runs; prints the file -> HBM "
                          "rate and is compared with the resident figure (never the headline value)")
+    ap.add_argument("--reuse-g-forward", action="store_true",
+                    help="OPT-IN, not the headline: one generator forward per step instead of the reference's two identical ones "
+                         "(GANTrainer.reuse_g_forward); the algorithmic work of the step is then 3 G-units + 8 D-units")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-floor", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -284,6 +287,7 @@ def main():
     mode = "Wasserstein" if args.loss == "wgan-gp" else "ModifiedMinMax"
     crit = losses.GANLoss(mode, n, device)
     trainer = GANTrainer(Gd, Dd, g_opt, d_opt, crit, losses.L1Loss(), loss_type_gan=mode, loss_weight_gp=10.0)
+    trainer.reuse_g_forward = bool(args.reuse_g_forward)
     if world > 1:   # what actually carries the gradients: the driver's torchrun line must show RCCL with N ranks
         devs = [None] * world
         dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} ({torch.cuda.get_device_name()})")
@@ -348,7 +352,8 @@ def main():
         "config": {"workload": f"{h}x{w}x{c} synthetic fields, batch {n}/GPU, DeepLabv3+/Xception-65 generator "
                                "(Interpolate upsampler, noise_dimensions 0) + Xception-65/Linear discriminator, "
                                "BatchNorm, " + ("Wasserstein + gradient penalty (weight 10) + L1" if args.loss == "wgan-gp" else "ModifiedMinMax + L1")
-                               + ", Adam(1e-4, eps 1e-8, wd 1e-5), D-step + G-step per step",
+                               + ", Adam(1e-4, eps 1e-8, wd 1e-5), D-step + G-step per step"
+                               + (" [OPT-IN --reuse-g-forward: one generator forward per step]" if args.reuse_g_forward else ""),
                    "global_batch": n * world, "parallelism": f"dp{world}", "last_d_loss": d_loss, "last_g_loss": g_loss,
                    "collective_backend": (dist.get_backend() if world > 1 else None)},
     }
@@ -429,7 +434,7 @@ def main():
             traffic = None
         cnt, secs, flops, _ = mfma[dom]
         achieved = flops / secs * 1e-12
-        walg = w_alg_tflop(h, w, c, args.loss)
+        walg = w_alg_tflop(h, w, c, args.loss, 3 if args.reuse_g_forward else 4)   # the work actually required in that mode
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "ridge_flop_per_byte": peak_of(dom) * 1e12 / 8e12, "achieved": achieved, "peak": peak_of(dom),
             "unit": "TFLOP/s", "frac": achieved / peak_of(dom), "traffic": traffic,

@@ -152,8 +152,10 @@ def norm_act_dw(owner: BGModule, m: nn.BatchNorm2d, x, stats, dw: "Conv2d"):
     """dw( LeakyReLU( m(x) ) ) in one pass over x (see norm_dw_fusable)."""
     a = owner.arena()
     groups = ops.current_bn_groups()
-    m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + groups
+    m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + groups * ops.current_bn_repeat()
     mom = 0.1 if m.momentum is None else float(m.momentum)
+    if ops.current_bn_repeat() > 1:
+        mom = 1.0 - (1.0 - mom) ** ops.current_bn_repeat()
     return ops.NormActDwConvFn.apply(x, m.weight, m.bias, dw.weight, a, a.by_param[id(m.weight)], a.by_param[id(m.bias)],
                                      a.by_param[id(dw.weight)], m.running_mean, m.running_var, True, float(m.eps), mom,
                                      stats, groups, dw.dilation[0])
@@ -205,8 +207,10 @@ def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False, stats=None
     if m.training:
         # counted on the host and folded into the buffer when state_dict() is taken
         # (74 one-element device increments per forward would only cost launches)
-        m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + groups
+        m.__dict__["_bg_nbt_pending"] = m.__dict__.get("_bg_nbt_pending", 0) + groups * ops.current_bn_repeat()
     mom = 0.1 if m.momentum is None else float(m.momentum)
+    if ops.current_bn_repeat() > 1:      # k identical forwards in one: the closed form of k momentum updates
+        mom = 1.0 - (1.0 - mom) ** ops.current_bn_repeat()
     return ops.NormActFn.apply(x, res, m.weight, m.bias, a, gs, bs, m.running_mean, m.running_var, "batch", m.training,
                                act, float(m.eps), mom, stats, groups)
 

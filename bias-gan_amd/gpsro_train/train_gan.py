@@ -56,6 +56,12 @@ class GANTrainer:
         # soon as the D-step's own (graph-free) generator forward is enqueued and runs under D's forward and
         # backward.  Only without host-drawn noise (the reference's RNG draw order is noise, labels, noise).
         self._g_ahead_ok = not os.environ.get("BGAMD_NO_G_PREFETCH")
+        # OPT-IN (off by default; not the measured headline): the reference evaluates the generator twice per iteration on
+        # the same input with unchanged weights (train_gan.py:252 and :275 -- G is not updated in between), so without
+        # host-drawn noise the second forward reproduces the first.  With reuse_g_forward the D-step's forward is run
+        # WITH its autograd graph and serves the G-step too; BatchNorm running statistics receive the two momentum
+        # updates in closed form (ops.bn_repeat) and num_batches_tracked counts two.  Saves one generator forward per step.
+        self.reuse_g_forward = bool(os.environ.get("BGAMD_REUSE_G_FORWARD"))
         self._g_ahead = None
         self._want_g_ahead = False
         self._d_params = [p for p in _unwrap(discriminator).parameters()]
@@ -70,15 +76,23 @@ class GANTrainer:
                 logits_fake, _ = self.discriminator(outputs_fake)
             return self._d_update(logits_real, logits_fake, outputs_fake, outputs_real, labels, eta)
         if self._batched_d and inputs.is_cuda:
-            outputs_fake = self._g_nograd(inputs)   # no autograd graph through G: D's update cannot use it
             n = outputs_real.shape[0]
+            if self.reuse_g_forward and self._want_g_ahead:
+                with ops.bn_repeat(2):
+                    fake_g = self.generator(inputs)          # ONE forward, with graph: this step's only one
+                self._g_ahead = (inputs, fake_g, False)
+                outputs_fake = fake_g.detach()
+                with ops.batch_groups(2):
+                    logits, _ = self.discriminator((outputs_real, outputs_fake))
+                return self._d_update(logits[:n], logits[n:], outputs_fake, outputs_real, labels, eta)
+            outputs_fake = self._g_nograd(inputs)   # no autograd graph through G: D's update cannot use it
             if self._want_g_ahead:
                 if self._side == "auto":
                     self._side = _side_stream(inputs.device, "generator-ahead")
                 if self._side is not None:
                     self._side.wait_stream(torch.cuda.current_stream(inputs.device))
                     with torch.cuda.stream(self._side):
-                        self._g_ahead = (inputs, self.generator(inputs))
+                        self._g_ahead = (inputs, self.generator(inputs), True)
             with ops.batch_groups(2):               # group 0 = real, group 1 = fake: the reference's call order
                 logits, _ = self.discriminator((outputs_real, outputs_fake))
             return self._d_update(logits[:n], logits[n:], outputs_fake, outputs_real, labels, eta)
@@ -143,9 +157,10 @@ class GANTrainer:
             ahead, self._g_ahead = self._g_ahead, None
             if ahead is not None and ahead[0] is inputs:
                 outputs_fake = ahead[1]
-                main = torch.cuda.current_stream(inputs.device)
-                main.wait_stream(self._side)
-                outputs_fake.record_stream(main)
+                if ahead[2]:      # computed on the side stream
+                    main = torch.cuda.current_stream(inputs.device)
+                    main.wait_stream(self._side)
+                    outputs_fake.record_stream(main)
             else:
                 outputs_fake = self.generator(inputs)
             # D's Adam update (and its gradient all-reduce) must land before D is used again
@@ -162,7 +177,7 @@ class GANTrainer:
                 g_loss = self.w_gan * gan_loss + self.w_reg * regression_loss
             self.g_opt.zero_grad()
             g_loss.backward()
-            if ahead is not None and ahead[0] is inputs:
+            if ahead is not None and ahead[0] is inputs and ahead[2]:
                 # the early generator forward ran on the side stream, so autograd runs its backward nodes there too;
                 # with the weight-gradient stream switched off nothing else joins that stream before Adam reads the gradients
                 torch.cuda.current_stream(inputs.device).wait_stream(self._side)

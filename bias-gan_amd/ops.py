@@ -712,6 +712,31 @@ def current_bn_groups() -> int:
     return _BN_GROUPS[-1]
 
 
+_BN_REPEAT = [1]
+
+
+class bn_repeat:
+    """Context: a training-mode BatchNorm forward counts as `k` identical forwards for its running statistics -- k momentum
+    updates with the same batch statistics, r <- (1-m)^k r + (1 - (1-m)^k) mu, and k counts of num_batches_tracked.  Used
+    when a trainer evaluates the generator once where the reference's loop evaluates it twice on the same input with
+    unchanged weights (train_gan.py:252,275; GANTrainer.reuse_g_forward)."""
+
+    def __init__(self, k: int):
+        self.k = int(k)
+
+    def __enter__(self):
+        _BN_REPEAT.append(self.k)
+        return self
+
+    def __exit__(self, *exc):
+        _BN_REPEAT.pop()
+        return False
+
+
+def current_bn_repeat() -> int:
+    return _BN_REPEAT[-1]
+
+
 
 class NormActFn(torch.autograd.Function):
     """y = act( norm(x) + res ).

@@ -1200,3 +1200,49 @@ def test_side_streams_are_dedicated_not_pool_streams():
             os.environ.pop("BGAMD_STEP_GRAPH", None)
         else:
             os.environ["BGAMD_STEP_GRAPH"] = old
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_reuse_g_forward_reproduces_the_two_forward_step(monkeypatch, dtype):
+    """GANTrainer.reuse_g_forward (opt-in, off by default): ONE generator forward per iteration instead of the reference's
+    two identical ones (train_gan.py:252,275 -- same input, G not updated in between, no host noise).  Losses, the
+    updated parameters and the BatchNorm buffers must be those of the two-forward step: running statistics receive both
+    momentum updates in closed form (equal to fp32 rounding), num_batches_tracked counts two."""
+    monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    c, h, w, n = 4, 64, 64, 2
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 700))
+
+    def run(reuse):
+        G, _ = build_generator(c, 41, dtype)
+        D, _ = build_discriminator(c, h, w, 42, dtype)
+        G.train(), D.train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        tr = GANTrainer(G, D, ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5), ph.get_optimizer(D.parameters(), "Adam", 1e-4, 1e-8, 1e-5),
+                        crit, losses.L1Loss())
+        tr.reuse_g_forward = reuse
+        L_ = __import__("bias_gan_amd._lib", fromlist=["x"])
+        L_.PROFILE = []
+        torch.manual_seed(3)
+        d_loss, g_loss = tr.step(x, y)
+        torch.cuda.synchronize()
+        names = [p[0] for p in L_.PROFILE]
+        L_.PROFILE = None
+        sd = {k: v.detach().float().cpu().clone() for k, v in G.state_dict().items()}
+        return float(d_loss), float(g_loss), sd, names.count("bg_nchw_to_nhwc")
+
+    a, b = run(False), run(True)
+    print(f"{dtype}: two forwards d {a[0]:.6f} g {a[1]:.6f} | one forward d {b[0]:.6f} g {b[1]:.6f}; layout-in launches {a[3]} vs {b[3]}")
+    assert b[3] < a[3], "the generator's input conversion should run once less"
+    tol = 1e-6 if dtype == F32 else 1e-5
+    assert abs(a[0] - b[0]) <= tol * abs(a[0]) and abs(a[1] - b[1]) <= tol * abs(a[1])
+    for k in a[2]:
+        if "num_batches_tracked" in k:
+            assert torch.equal(a[2][k], b[2][k]) and float(a[2][k]) == 2.0, (k, a[2][k], b[2][k])
+        elif "running_" in k:
+            assert rel_err(b[2][k], a[2][k]) <= 2e-6, (k, rel_err(b[2][k], a[2][k]))
+        else:
+            # parameters after the first Adam step, which is sign-like (+-lr = 1e-4 per weight): the same gradients up to the
+            # arrival order of the weight gradients' fp32 atomics, so a weight whose gradient is at rounding level may take
+            # the other sign (two runs of the SAME configuration differ the same way) -- at most 2 lr, on a handful
+            diff = (b[2][k] - a[2][k]).abs()
+            assert float(diff.max()) <= 2.1e-4 and float((diff > 1e-5).float().mean()) <= 2e-3, (k, float(diff.max()), float((diff > 1e-5).float().mean()))
