@@ -1086,7 +1086,8 @@ def test_conv_split_k(case, dtype):
 
 @pytest.mark.parametrize("with_dw", [True, False])
 @pytest.mark.parametrize("case", [(4, 13, 18, 16, 1, 2, 1), (2, 9, 7, 728, 1, 1, 1), (4, 16, 12, 24, 2, 2, 1), (2, 6, 5, 40, 1, 1, 0),
-                                  (2, 11, 50, 264, 1, 1, 2), (2, 72, 48, 728, 1, 1, 1), (2, 37, 101, 136, 2, 1, 1), (3, 5, 130, 72, 1, 3, 1)])
+                                  (2, 11, 50, 264, 1, 1, 2), (2, 72, 48, 728, 1, 1, 1), (2, 37, 101, 136, 2, 1, 1), (3, 5, 130, 72, 1, 3, 1),
+                                  (4, 72, 48, 728, 1, 2, 1)])     # last: 72 tiles per slab on 21 workgroups -> a workgroup's tiles cross the statistic groups
 def test_dwconv_bwd_fused_matches_the_three_kernels(case, with_dw):
     """bg_dwconv3x3_bwd_fused (one pass over dy and x: data gradient, weight gradient on the recomputed activation and
     the two BatchNorm-backward statistics) against the three round-2 kernels it replaces -- bg_dwconv3x3_bwd_data,
