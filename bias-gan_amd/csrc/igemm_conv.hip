@@ -923,30 +923,55 @@ struct WgGangParams {
     int KS;                 // K-steps (32 pixels) per layer
     int R;                  // K-steps per gang
     int gangs;              // ranges of the (layer, pixel) space
-    int gpx;                // > 0: gangs per XCD -- the T workgroups of a gang sit on ONE XCD (same blockIdx % 8), so the
-                            // rows the T tiles share come out of that XCD's L2 (each dy / x row is wanted by 3 of the 9
-                            // tiles of a 728 x 728 layer; spread over the XCDs every one of them went to the fabric and
-                            // the launch was bound by that traffic at 390 TFLOP/s)
+    int use_map;            // 1: (gang, member) of a workgroup come from `map` (XCD-local placement), 0: blockIdx / tiles
+    unsigned short map[256];   // blockIdx -> gang << 8 | member, 0xffff = idle.  Workgroup b runs on XCD b % 8: the launcher
+                            // puts the T workgroups of a gang on ONE XCD, so the rows the tiles share (each dy / x row is wanted
+                            // by 3 of the 9 tiles of a 728 x 728 layer) are fetched once into that XCD's L2 -- spread over the
+                            // XCDs every copy went to the fabric: 7.3 GB fetched for 3.9 GB of operands (rocprofv3 FETCH_SIZE),
+                            // XCD-local 3.86 GB.  The CUs an XCD has left over (32 - 3 x 9 = 5) form gangs that straddle two
+                            // neighbouring XCDs, so 252 of the 256 CUs work.
 };
 
 constexpr int WGG_PIX = 32, WGG_ROWB = 512, WGG_OP = WGG_PIX * WGG_ROWB, WGG_STAGE = 2 * WGG_OP;
 
+// One MFMA 32x32x16 operand fragment of 16-pixel half H: two transposing 8-byte reads (pixel rows r and r + 4 of the half).
+template <int OFF>
+__device__ __forceinline__ s16x4 wgg_tr16(unsigned addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int H>
+__device__ __forceinline__ bf16x8 wgg_frag(unsigned addr, int kt, int lane) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+#ifdef ABL_G_NO_FRAG   // ablation: no LDS reads, the MFMAs take a register pattern
+    s16x8 tt = {(short)addr, (short)kt, (short)lane, 1, 2, 3, 4, 5};
+    asm volatile("" : "+v"(tt));
+    return __builtin_bit_cast(bf16x8, tt);
+#else
+    (void)kt; (void)lane;
+    const s16x4 lo = wgg_tr16<H * 16 * WGG_ROWB>(addr);
+    const s16x4 hi = wgg_tr16<H * 16 * WGG_ROWB + 4 * WGG_ROWB>(addr);
+    const s16x8 tt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, tt);
+#endif
+}
+
 template <int WGG_NBUF>
 __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    typedef __attribute__((address_space(3))) char* lds_char_p;
     constexpr int GROUP = 4, DIST = WGG_NBUF - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds_base = (unsigned)(size_t)(lds_char_p)smem;   // byte address of the ring inside the LDS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;      // 2 x 4 waves: 128 (co) x 64 (ci) each
     int gang, member;
-    if (P.gpx > 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int gi_ = slot / P.tiles;
-        member = slot - gi_ * P.tiles;
-        if (gi_ >= P.gpx) return;       // the XCD's left-over CUs
-        gang = xcd * P.gpx + gi_;
+    if (P.use_map) {
+        const unsigned gm = P.map[blockIdx.x];
+        if (gm == 0xffffu) return;      // a left-over CU
+        gang = gm >> 8;
+        member = gm & 255;
     } else {
         gang = blockIdx.x / P.tiles;
         member = blockIdx.x - gang * P.tiles;
@@ -998,8 +1023,16 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
         const int step_a = WGG_PIX * P.ldy * 2, step_b = WGG_PIX * P.ldx * 2;
         auto piece = [&](int buf, int pi) {   // pi compile-time: 0, 1 = dy pieces, 2, 3 = x pieces
             char* st = smem + buf * WGG_STAGE + (pi >= 2 ? WGG_OP : 0) + (2 * wave + 16 * (pi & 1)) * WGG_ROWB;
+#if defined(ABL_G_SKIP_DMA)    // ablation builds (scripts/ablate_gang.sh): no DMA instruction at all
+            (void)st;
+#elif defined(ABL_G_NO_DMA)    // the instruction issues, every lane out of range: no memory traffic
+            dma16(rs_a, st, OOB);
+#elif defined(ABL_G_HOT)       // every piece re-reads the segment's first rows (L2-resident operands)
+            if (pi < 2) dma16(rs_a, st, va[pi]); else dma16(rs_b, st, vb[pi - 2]);
+#else
             if (pi < 2) { dma16(rs_a, st, va[pi]); va[pi] += step_a; }
             else { dma16(rs_b, st, vb[pi - 2]); vb[pi - 2] += step_b; }
+#endif
         };
         f32x16 acc[4][2];
 #pragma unroll
@@ -1016,44 +1049,85 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
 #pragma unroll
                 for (int pi = 0; pi < GROUP; ++pi) piece(s_, pi);
             }
+        // K loop, software-pipelined across the K-steps: a step's barrier sits in its MIDDLE.  The fragments of a
+        // 16-pixel half are read one half-step before their MFMAs (eight MFMAs of the wave cover the LDS latency), and the
+        // wait for the next stage's pieces + the workgroup barrier come after the first half's MFMAs, when the second
+        // half's operands are already in registers: a wave leaves the barrier straight into MFMAs.  (With the barrier at
+        // the top of the step both waves of a SIMD stood behind it with empty hands: 12 reads and their latency, every
+        // step, with the matrix pipe idle -- 1 500 cycles per step against 1 024 of MFMA even without any DMA.)
+        //   ring safety: pieces issued in step kt go to the buffer of stage kt + DIST = the buffer read in step kt - 1,
+        //   whose last reads every wave has waited for before the mid-step barrier of kt - 1;
+        //   the reads of stage kt + 1 start after the mid-step barrier of kt, behind every wave's own counted vmcnt.
         int buf = 0, nbuf = DIST % WGG_NBUF;
-        for (int kt = 0; kt < KT; ++kt) {
-            const int ahead = KT - 1 - kt;
-            if (DIST >= 4 && ahead >= 3) wait_vmcnt<3 * GROUP>();
-            else if (ahead >= 2) wait_vmcnt<2 * GROUP>();
-            else if (ahead >= 1) wait_vmcnt<GROUP>();
+        bf16x8 fa[2][4], fb[2][2];
+        auto stage_addr = [&](int bf, unsigned (&ad_a)[4], unsigned (&ad_b)[2]) {
+            const unsigned sbase = lds_base + bf * WGG_STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ad_a[i] = sbase + off_a[i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ad_b[j] = sbase + off_b[j];
+        };
+        // Fragment reads are inline assembly ON PURPOSE: LLVM's waitcnt pass cannot prove that an LDS read carrying a memory
+        // operand does not alias the destination of an outstanding `buffer_load ... lds`, so it put `s_waitcnt vmcnt(0)`
+        // in front of every ds_read_b64_tr_b16 intrinsic -- each K-step waited for ALL pieces in flight, those issued a
+        // moment before included, and the ring had no depth at all (scripts/find_dma_waits.py lists such waits).  The
+        // ring's counted vmcnt + barrier order the DMA writes against these reads; lgkmcnt is counted by hand (the LDS
+        // returns in order and the loop holds no scalar loads).
+        {   // stage 0 has landed everywhere; first half of step 0
+            if (KT > 2) wait_vmcnt<2 * GROUP>();
+            else if (KT > 1) wait_vmcnt<GROUP>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            const bool more = kt + DIST < KT;
-            const char* st = smem + buf * WGG_STAGE;
-            auto frag = [&](int off) -> bf16x8 {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + off + 4 * WGG_ROWB));
-                const s16x8 tt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                return __builtin_bit_cast(bf16x8, tt);
-            };
-            // both 16-pixel halves' fragments: the first half is read behind the barrier, the second while the first
-            // half's MFMAs run (a read issued right in front of its MFMAs exposed the LDS latency eight times per step)
-            bf16x8 fa[2][4], fb[2][2];
+            unsigned ad_a[4], ad_b[2];
+            stage_addr(0, ad_a, ad_b);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[0][j] = frag(off_b[j]);
+            for (int j = 0; j < 2; ++j) fb[0][j] = wgg_frag<0>(ad_b[j], 0, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[0][i] = frag(off_a[i]);
+            for (int i = 0; i < 4; ++i) fa[0][i] = wgg_frag<0>(ad_a[i], 0, lane);
+        }
+        for (int kt = 0; kt < KT; ++kt) {
+            const int ahead = KT - 1 - kt;
+            const bool more = ahead >= DIST;
+            unsigned ad_a[4], ad_b[2];
+            stage_addr(buf, ad_a, ad_b);
+            // second half's fragments of this step
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[1][j] = wgg_frag<1>(ad_b[j], kt, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[1][i] = wgg_frag<1>(ad_a[i], kt, lane);
+            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]));
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1]));
+                    if (ahead >= 1) {
+                        // stage kt + 1 complete: stages kt + 2 .. kt + DIST - 1 and this step's first two pieces may stay in flight
+                        if (ahead >= DIST) wait_vmcnt<(DIST - 2) * GROUP + GROUP / 2>();
+                        else if (DIST >= 4 && ahead >= 3) wait_vmcnt<2 * GROUP>();
+                        else if (ahead >= 2) wait_vmcnt<GROUP>();
+                        else wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        const int b1 = (buf + 1 == WGG_NBUF) ? 0 : buf + 1;
+                        stage_addr(b1, ad_a, ad_b);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) fb[0][j] = wgg_frag<0>(ad_b[j], kt, lane);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[0][i] = wgg_frag<0>(ad_a[i], kt, lane);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && (i & 1) == 0) piece(nbuf, ks * 2 + (i >> 1));   // 4 pieces over the 8 MFMA groups of a step
-                    if (ks == 0 && i == 0) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) fb[1][j] = frag(off_b[j] + 16 * WGG_ROWB);
-#pragma unroll
-                        for (int i2 = 0; i2 < 4; ++i2) fa[1][i2] = frag(off_a[i2] + 16 * WGG_ROWB);
-                    }
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+#ifdef ABL_G_NO_MFMA   // ablation: the fragments are consumed by one VALU op each instead of the MFMAs
+                        acc[i][j][0] += __builtin_bit_cast(f32x4, fa[ks][i])[0] * __builtin_bit_cast(f32x4, fb[ks][j])[1];
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+#endif
+                    }
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
@@ -1481,12 +1555,24 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
         BG_CHECK_ARG(P.tiles <= 256, "bg_conv2d_bwd_weight_grouped: more than 256 output tiles per layer");
         P.KS = (int)((M + WGG_PIX - 1) / WGG_PIX);
         const long long total = (long long)P.L * P.KS;
-        // XCD-local gangs only on request: measured, the launch is bound by its K loop, not by the fabric -- the same time
-        // per workgroup either way, and the spread form uses 252 of the CUs where 3 gangs of 9 per XCD use 216 (695
-        // against 615 TFLOP/s)
-        static const bool xcd_local = getenv("BGAMD_WGG_XCD_LOCAL") != nullptr;
-        P.gpx = xcd_local && P.tiles <= 32 && P.tiles > 1 ? 32 / P.tiles : 0;
-        long long gangs = P.gpx ? 8 * P.gpx : 256 / P.tiles;            // one workgroup per CU
+        // Placement.  T <= 32 tiles per layer: XCD-local gangs (struct comment) -- g = 32 / T whole gangs per XCD plus
+        // gangs made of the left-over CUs of q neighbouring XCDs; otherwise gangs spread in blockIdx order.
+        static const bool spread_only = getenv("BGAMD_WGG_SPREAD") != nullptr;
+        const int T = P.tiles;
+        long long gangs;
+        int gpx = 0, q = 0;
+        P.use_map = !spread_only && T > 1 && T <= 32;
+        if (P.use_map) {
+            gpx = 32 / T;
+            const int left = 32 - gpx * T;
+            if (left > 0) {
+                q = 1;
+                while (q * left < T) q *= 2;          // q in {1, 2, 4, 8, ...}: XCDs pooled per straddling gang
+                if (q > 8) q = 0;
+            }
+            gangs = 8 * gpx + (q ? 8 / q : 0);
+        } else
+            gangs = 256 / T;            // one workgroup per CU
         // A group of at least as many layers as gangs gives every gang a range of at least one layer: every dW tile then
         // receives at most two adds (order-independent: bit-reproducible).  Smaller groups keep all the gangs -- several
         // ranges per layer, their adds land in any order.  At least 8 K-steps per range.
@@ -1494,7 +1580,25 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
         P.R = (int)((total + gangs - 1) / gangs);
         gangs = (total + P.R - 1) / P.R;
         P.gangs = (int)gangs;
-        const long long grid = P.gpx ? 256 : gangs * P.tiles;
+        long long grid = gangs * T;
+        if (P.use_map) {
+            for (int b = 0; b < 256; ++b) P.map[b] = 0xffff;
+            int gi = 0;
+            // whole gangs: gang (x, k) takes slots k*T .. k*T + T - 1 of XCD x; gangs numbered XCD-major so that a short
+            // group (fewer ranges than gangs) still spreads over all XCDs
+            for (int k = 0; k < gpx; ++k)
+                for (int x = 0; x < 8; ++x, ++gi)
+                    for (int m = 0; m < T; ++m) P.map[(k * T + m) * 8 + x] = (unsigned short)(gi << 8 | m);
+            // straddling gangs: consecutive members (row-major tiles: neighbours share their dy rows) fill the left-over
+            // slots of XCDs c*q .. c*q + q - 1 in order
+            if (q)
+                for (int c = 0; c < 8 / q; ++c, ++gi) {
+                    int m = 0;
+                    for (int x = c * q; x < (c + 1) * q && m < T; ++x)
+                        for (int sl = gpx * T; sl < 32 && m < T; ++sl, ++m) P.map[sl * 8 + x] = (unsigned short)(gi << 8 | m);
+                }
+            grid = 256;
+        }
         if (nbuf == 4) hipLaunchKernelGGL(wgrad_gang_kernel<4>, dim3((unsigned)grid), dim3(512), 4 * WGG_STAGE, (hipStream_t)stream, P);
         else hipLaunchKernelGGL(wgrad_gang_kernel<5>, dim3((unsigned)grid), dim3(512), 5 * WGG_STAGE, (hipStream_t)stream, P);
         BG_CHECK_LAUNCH("wgrad_gang_kernel");

@@ -9,7 +9,7 @@ from bias_gan_amd import _lib as L
 CASES = [(48, 8 * 72 * 48, 728, 728), (48, 16 * 72 * 48, 728, 728), (1, 8 * 72 * 48, 1536, 1536), (1, 8 * 72 * 48, 1536, 2048),
          (1, 8 * 72 * 48, 728, 1024), (1, 8 * 144 * 96, 728, 728), (1, 8 * 288 * 192, 256, 256), (1, 8 * 576 * 384, 128, 128),
          (1, 16 * 576 * 384, 128, 128), (1, 8 * 72 * 48, 2048, 256), (1, 8 * 72 * 48, 1280, 256)]
-for nl, m, cin, cout in CASES:
+for nl, m, cin, cout in CASES[:int(os.environ.get('CASES_ONLY', len(CASES)))]:
     nbuf = min(nl, 6)   # operands of the group's layers: a few distinct buffers reused (memory)
     xs = [torch.randn(m, cin, device="cuda").bfloat16() for _ in range(nbuf)]
     gs = [(torch.randn(m, cout, device="cuda") * 0.01).bfloat16() for _ in range(nbuf)]
