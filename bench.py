@@ -375,11 +375,12 @@ def main():
         for _ in range(2):
             if rank == 0:
                 L.PROFILE = []
+                L.PROFILE_SHAPES = [] if args.dump_launches else None
             trainer.step(*batches[0])
             torch.cuda.synchronize()
             if rank == 0:
                 prof.append([(nm, fl, e0.elapsed_time(e1), nb) for nm, fl, e0, e1, nb in L.PROFILE])
-                L.PROFILE = None
+                shapes, L.PROFILE, L.PROFILE_SHAPES = L.PROFILE_SHAPES, None, None
         trainer._side = side
     if rank == 0 and not args.no_kernel_profile:
         a, b = prof
@@ -392,8 +393,8 @@ def main():
         recs = [(nm, fl, _Ev(0.0), _Ev(ms), nb) for nm, fl, ms, nb in a]
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
-                for name, flops, e0, e1, nbytes in recs:
-                    f.write(f"{name} {flops:.0f} {nbytes:.0f} {e0.elapsed_time(e1):.5f}\n")
+                for i, (name, flops, e0, e1, nbytes) in enumerate(recs):
+                    f.write(f"{name} {flops:.0f} {nbytes:.0f} {e0.elapsed_time(e1):.5f} {shapes[i] if shapes and len(shapes) == len(recs) else '-'}\n")
         fam = {}
         for name, flops, e0, e1, nbytes in recs:
             f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])

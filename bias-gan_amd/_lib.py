@@ -58,6 +58,7 @@ _SIGS = {
     "bg_conv2d_bwd_data": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight_grouped": [c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_conv2d_bwd_weight_grouped_taps": [C.POINTER(ConvDesc), c_vp, c_i32, c_vp],
     "bg_pack_conv_weights": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
     "bg_quant_fp8": [c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "bg_fp8_roll": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
@@ -212,6 +213,7 @@ def stream():
 # kernel is launched on (torch's current stream IS that stream): bench.py uses it for
 # the per-kernel durations of its roofline object.  None (default) = no overhead.
 PROFILE = None
+PROFILE_SHAPES = None
 
 
 def _conv_flops(desc) -> float:
@@ -228,6 +230,9 @@ def _alg_bytes(name, a) -> float:
     nn = lambda *idx: sum(1 for i in idx if a[i] is not None)  # noqa: E731
     if name == "bg_conv2d_bwd_weight_grouped":
         return float(a[2]) * (float(a[3]) * (a[4] + a[5]) * 2 + 4.0 * a[4] * a[5])
+    if name == "bg_conv2d_bwd_weight_grouped_taps":   # x and dy once, fp32 dW once, per layer
+        d = a[0]
+        return float(a[2]) * (float(d.N) * d.H * d.W * (d.Cin + d.Cout) * 2 + 4.0 * d.Cout * d.Cin * d.KH * d.KW)
     if name == "bg_conv2d_fwd_fp8":       # fp8 bytes in, fp8 weights, bf16 out
         d = a[0]
         return float(d.N) * (d.H * d.W * d.Cin + 2 * d.Ho * d.Wo * d.Cout) + d.Cout * d.Cin * d.KH * d.KW
@@ -318,9 +323,14 @@ def call(name, *args):
         e1.record()
         if name == "bg_conv2d_bwd_weight_grouped":
             flops = 2.0 * args[2] * args[3] * args[4] * args[5]
+        elif name == "bg_conv2d_bwd_weight_grouped_taps":
+            flops = _conv_flops(args[0]) * args[2]
         else:
             flops = _conv_flops(args[0]) if name.startswith("bg_conv2d") else 0.0
         PROFILE.append((name, flops, e0, e1, _alg_bytes(name, args)))
+        if PROFILE_SHAPES is not None:      # bench.py --dump-launches: which layer a convolution launch was
+            d = args[0]
+            PROFILE_SHAPES.append(f"{d.N}x{d.H}x{d.W},{d.Cin}->{d.Cout},k{d.KH}s{d.stride}d{d.dil}" if isinstance(d, ConvDesc) else "-")
     else:
         rc = fn(*args, stream())
     if rc != 0:

@@ -917,8 +917,16 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
 // by (row & 3) << 1 on the source side, which makes the transposing reads conflict-free without row padding.
 constexpr int WGG_MAX_LAYERS = 64;
 struct WgGangParams {
-    long long tbl[WGG_MAX_LAYERS][3];   // x, dy, dw addresses per layer: in the kernel arguments (1.5 KB), no table in memory
+    long long tbl[WGG_MAX_LAYERS][4];   // x, dy, dw addresses per layer (+ its tap, when taps travel as layers): in the kernel
+                                        // arguments (2 KB), no table in memory
     int L, M, ldx, ldy, Ci, Co;
+    // k x k convolutions (stride 1, "same" padding; TAPS kernels): a tap (r, s) is a 1x1 weight gradient against x shifted
+    // by ((r - KH/2) * dil) rows and ((s - KW/2) * dil) columns, border pixels masked.  With few tiles the RS taps are
+    // MEMBERS of the gang (taps_in_members: the nine workgroups walk the same pixels together, dy and the nine shifted
+    // windows of x come out of one L2), otherwise every tap is a layer of its own (tbl[l][3]).
+    int N, H, W, KH, KW, dil, RS;
+    int tpt;                // tiles per tap (= tiles_co * tiles_ci)
+    int taps_in_members;
     int tiles_ci, tiles;    // tiles per layer
     int KS;                 // K-steps (32 pixels) per layer
     int R;                  // K-steps per gang
@@ -957,7 +965,7 @@ __device__ __forceinline__ bf16x8 wgg_frag(unsigned addr, int kt, int lane) {
 #endif
 }
 
-template <int WGG_NBUF>
+template <int WGG_NBUF, bool TAPS>
 __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
     typedef __attribute__((address_space(3))) char* lds_char_p;
     constexpr int GROUP = 4, DIST = WGG_NBUF - 1;
@@ -977,6 +985,11 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
         member = blockIdx.x - gang * P.tiles;
     }
     if (gang >= P.gangs) return;
+    int tap_m = 0;
+    if (TAPS && P.taps_in_members) {
+        tap_m = member / P.tpt;
+        member -= tap_m * P.tpt;
+    }
     const int tile_co = member / P.tiles_ci, tile_ci = member - tile_co * P.tiles_ci;
     const int co_base = tile_co * 256, ci_base = tile_ci * 256;
     const long long total = (long long)P.L * P.KS;
@@ -1009,16 +1022,33 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
         float* dw = reinterpret_cast<float*>(P.tbl[l][2]);
         // descriptors rebased to the segment's first pixel; rows beyond M are out of range = zeros
         const long long p0 = (long long)ks0 * WGG_PIX;
-        const long long rem_a = (((long long)P.M - p0 - 1) * P.ldy + P.Co) * 2, rem_b = (((long long)P.M - p0 - 1) * P.ldx + P.Ci) * 2;
+        int tap = 0, dr = 0, dc = 0;
+        long long shift = 0;            // rows between a dy pixel and the x pixel its tap multiplies
+        if (TAPS) {
+            tap = P.taps_in_members ? tap_m : (int)P.tbl[l][3];
+            const int r = tap / P.KW, s_ = tap - r * P.KW;
+            dr = (r - (P.KH >> 1)) * P.dil;
+            dc = (s_ - (P.KW >> 1)) * P.dil;
+            shift = (long long)dr * P.W + dc;
+        }
+        const long long rem_a = (((long long)P.M - p0 - 1) * P.ldy + P.Co) * 2,
+                        rem_b = (((long long)P.M - p0 - shift - 1) * P.ldx + P.Ci) * 2;
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<bf16_t*>(dyp + p0 * P.ldy), 0, (int)(rem_a < 0x7fffffffLL ? rem_a : 0x7fffffffLL), 0x00020000);
+        // (with a negative shift the base lies in front of the tensor for the first rows: those lanes are masked below)
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(xp + p0 * P.ldx), 0, (int)(rem_b < 0x7fffffffLL ? rem_b : 0x7fffffffLL), 0x00020000);
+            const_cast<bf16_t*>(xp + (p0 + shift) * P.ldx), 0, (int)(rem_b < 0x7fffffffLL ? rem_b : 0x7fffffffLL), 0x00020000);
         int va[2], vb[2];
+        int xn[2], xh[2], xw[2];        // TAPS: image, row, column of the dy pixel each x piece row belongs to
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             va[k] = a_ok ? ((row_a + 16 * k) * P.ldy + co_base + chunk * 8) * 2 : OOB;
             vb[k] = b_ok ? ((row_a + 16 * k) * P.ldx + ci_base + chunk * 8) * 2 : OOB;
+            if (TAPS) {
+                const unsigned pu = (unsigned)(p0 + row_a + 16 * k), hw = (unsigned)(P.H * P.W);
+                const unsigned n_ = pu / hw, rem = pu - n_ * hw, h_ = rem / (unsigned)P.W;
+                xn[k] = (int)n_; xh[k] = (int)h_; xw[k] = (int)(rem - h_ * (unsigned)P.W);
+            }
         }
         const int step_a = WGG_PIX * P.ldy * 2, step_b = WGG_PIX * P.ldx * 2;
         auto piece = [&](int buf, int pi) {   // pi compile-time: 0, 1 = dy pieces, 2, 3 = x pieces
@@ -1031,7 +1061,18 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
             if (pi < 2) dma16(rs_a, st, va[pi]); else dma16(rs_b, st, vb[pi - 2]);
 #else
             if (pi < 2) { dma16(rs_a, st, va[pi]); va[pi] += step_a; }
-            else { dma16(rs_b, st, vb[pi - 2]); vb[pi - 2] += step_b; }
+            else if (!TAPS) { dma16(rs_b, st, vb[pi - 2]); vb[pi - 2] += step_b; }
+            else {
+                const int k = pi - 2;
+                const bool in = xn[k] < P.N && (unsigned)(xh[k] + dr) < (unsigned)P.H && (unsigned)(xw[k] + dc) < (unsigned)P.W;
+                dma16(rs_b, st, in ? vb[k] : OOB);
+                vb[k] += step_b;
+                xw[k] += WGG_PIX;
+                while (xw[k] >= P.W) {
+                    xw[k] -= P.W;
+                    if (++xh[k] == P.H) { xh[k] = 0; ++xn[k]; }
+                }
+            }
 #endif
         };
         f32x16 acc[4][2];
@@ -1139,13 +1180,14 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
         // Buffer atomics over a descriptor of exactly this layer's dW: rows beyond Cout fall out of its range, lanes
         // beyond Cin carry the out-of-range marker -- no exec-mask branches, one VALU add per atomic.
         {
-            const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(dw, 0, P.Co * P.Ci * 4, 0x00020000);
+            // dW is [Co][RS][Ci]: this tap's columns start at tap * Ci, a row is RS * Ci wide
+            const int rowb = P.RS * P.Ci * 4;
+            const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(dw + tap * P.Ci, 0, (P.Co - 1) * rowb + P.Ci * 4, 0x00020000);
             const int c32 = lane & 31, h2 = lane >> 5;
-            const int rowb = P.Ci * 4;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ci = ci_base + wave_n * 64 + j * 32 + c32;
-                int lane_off = ci < P.Ci ? ((co_base + wave_m * 128 + 4 * h2) * P.Ci + ci) * 4 : OOB;
+                int lane_off = ci < P.Ci ? (co_base + wave_m * 128 + 4 * h2) * rowb + ci * 4 : OOB;
                 asm volatile("" : "+v"(lane_off));   // keeps the 64 derived offsets out of the segment loop's invariants (they spilled)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -1526,37 +1568,50 @@ extern "C" int bg_conv_set_variant(int32_t variant) {
     return BG_OK;
 }
 
-extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, int32_t n_layers, int64_t M, int32_t Cin,
-                                           int32_t Cout, int32_t ldx, int32_t ldy, void* stream) {
-    BG_CHECK_ARG(dtype == BG_BF16, "bg_conv2d_bwd_weight_grouped: bf16 operands only (the transposing LDS reads)");
-    BG_CHECK_ARG(tbl && n_layers >= 1 && M >= 1 && M < (1LL << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 &&
-                 ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, "bg_conv2d_bwd_weight_grouped: bad arguments");
-    // the kernel addresses a layer's operands with 32-bit byte offsets into per-layer descriptors
-    BG_CHECK_ARG((M - 1) * (long long)ldx * 2 + (long long)Cin * 2 < (1LL << 31) && (M - 1) * (long long)ldy * 2 + (long long)Cout * 2 < (1LL << 31),
-                 "bg_conv2d_bwd_weight_grouped: an operand beyond 2 GiB (M=%lld ldx=%d ldy=%d)", (long long)M, ldx, ldy);
-    static const int nbuf = getenv("BGAMD_WGG_NBUF") ? atoi(getenv("BGAMD_WGG_NBUF")) : 4;   // 4 or 5 stages of 32 KiB (measured: 5 is +2 % on the 48-layer group, -4 % on single layers)
+// Geometry of a grouped weight-gradient launch: RS = 1 is the pointwise case (M pixels, no image structure).
+struct WggGeom { long long M; int N, H, W, KH, KW, dil, Cin, Cout, ldx, ldy; };
+
+static int launch_wgrad_gang(const char* who, const int64_t* tbl, int n_layers, const WggGeom& G, void* stream) {
+    const int RS = G.KH * G.KW;
+    const bool taps = RS > 1;
+    static const int nbuf = getenv("BGAMD_WGG_NBUF") ? atoi(getenv("BGAMD_WGG_NBUF")) : 4;   // 4 or 5 stages of 32 KiB
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WGG_STAGE);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * WGG_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WGG_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * WGG_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WGG_STAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gang_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * WGG_STAGE);
         once = true;
     }
-    for (int l0 = 0; l0 < n_layers; l0 += WGG_MAX_LAYERS) {     // the addresses travel in the kernel arguments: 64 layers per launch
+    const int tiles_ci = (G.Cin + 255) / 256, tpt = tiles_ci * ((G.Cout + 255) / 256);
+    BG_CHECK_ARG(tpt <= 256, "%s: more than 256 output tiles per layer", who);
+    // few tiles: the taps are members of the gang; otherwise every (layer, tap) pair is a layer of the launch
+    const bool taps_in_members = taps && RS * tpt <= 32;
+    const int per_layer = taps && !taps_in_members ? RS : 1;             // launch layers per caller layer
+    const int chunk = WGG_MAX_LAYERS / per_layer;                          // caller layers per launch
+    for (int l0 = 0; l0 < n_layers; l0 += chunk) {     // the addresses travel in the kernel arguments: 64 layers per launch
         WgGangParams P{};
-        P.L = std::min(WGG_MAX_LAYERS, n_layers - l0);
-        for (int l = 0; l < P.L; ++l)
-            for (int k = 0; k < 3; ++k) {
-                P.tbl[l][k] = tbl[(long long)(l0 + l) * 4 + k];
-                BG_CHECK_ARG(P.tbl[l][k] != 0 && (P.tbl[l][k] & 15) == 0, "bg_conv2d_bwd_weight_grouped: null/unaligned pointer in row %d", l0 + l);
+        const int nl = std::min(chunk, n_layers - l0);
+        P.L = nl * per_layer;
+        for (int l = 0; l < nl; ++l) {
+            for (int k = 0; k < 3; ++k)
+                BG_CHECK_ARG(tbl[(long long)(l0 + l) * 4 + k] != 0 && (tbl[(long long)(l0 + l) * 4 + k] & 15) == 0,
+                             "%s: null/unaligned pointer in row %d", who, l0 + l);
+            for (int t = 0; t < per_layer; ++t) {
+                for (int k = 0; k < 3; ++k) P.tbl[l * per_layer + t][k] = tbl[(long long)(l0 + l) * 4 + k];
+                P.tbl[l * per_layer + t][3] = t;
             }
-        P.M = (int)M; P.ldx = ldx; P.ldy = ldy; P.Ci = Cin; P.Co = Cout;
-        P.tiles_ci = (Cin + 255) / 256;
-        P.tiles = P.tiles_ci * ((Cout + 255) / 256);
-        BG_CHECK_ARG(P.tiles <= 256, "bg_conv2d_bwd_weight_grouped: more than 256 output tiles per layer");
-        P.KS = (int)((M + WGG_PIX - 1) / WGG_PIX);
+        }
+        P.M = (int)G.M; P.ldx = G.ldx; P.ldy = G.ldy; P.Ci = G.Cin; P.Co = G.Cout;
+        P.N = G.N; P.H = G.H; P.W = G.W; P.KH = G.KH; P.KW = G.KW; P.dil = G.dil; P.RS = RS;
+        P.tiles_ci = tiles_ci;
+        P.tpt = tpt;
+        P.taps_in_members = taps_in_members;
+        P.tiles = taps_in_members ? RS * tpt : tpt;     // members of a gang
+        P.KS = (int)((G.M + WGG_PIX - 1) / WGG_PIX);
         const long long total = (long long)P.L * P.KS;
-        // Placement.  T <= 32 tiles per layer: XCD-local gangs (struct comment) -- g = 32 / T whole gangs per XCD plus
-        // gangs made of the left-over CUs of q neighbouring XCDs; otherwise gangs spread in blockIdx order.
+        // Placement.  T <= 32 members: XCD-local gangs (struct comment) -- g = 32 / T whole gangs per XCD plus gangs made
+        // of the left-over CUs of q neighbouring XCDs; otherwise gangs spread in blockIdx order.
         static const bool spread_only = getenv("BGAMD_WGG_SPREAD") != nullptr;
         const int T = P.tiles;
         long long gangs;
@@ -1572,7 +1627,7 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
             }
             gangs = 8 * gpx + (q ? 8 / q : 0);
         } else
-            gangs = 256 / T;            // one workgroup per CU
+            gangs = std::max(1, 256 / T);            // one workgroup per CU
         // A group of at least as many layers as gangs gives every gang a range of at least one layer: every dW tile then
         // receives at most two adds (order-independent: bit-reproducible).  Smaller groups keep all the gangs -- several
         // ranges per layer, their adds land in any order.  At least 8 K-steps per range.
@@ -1599,11 +1654,52 @@ extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, i
                 }
             grid = 256;
         }
-        if (nbuf == 4) hipLaunchKernelGGL(wgrad_gang_kernel<4>, dim3((unsigned)grid), dim3(512), 4 * WGG_STAGE, (hipStream_t)stream, P);
-        else hipLaunchKernelGGL(wgrad_gang_kernel<5>, dim3((unsigned)grid), dim3(512), 5 * WGG_STAGE, (hipStream_t)stream, P);
+        const dim3 gr((unsigned)grid), bl(512);
+        hipStream_t st = (hipStream_t)stream;
+        if (taps) {
+            if (nbuf == 4) hipLaunchKernelGGL((wgrad_gang_kernel<4, true>), gr, bl, 4 * WGG_STAGE, st, P);
+            else hipLaunchKernelGGL((wgrad_gang_kernel<5, true>), gr, bl, 5 * WGG_STAGE, st, P);
+        } else {
+            if (nbuf == 4) hipLaunchKernelGGL((wgrad_gang_kernel<4, false>), gr, bl, 4 * WGG_STAGE, st, P);
+            else hipLaunchKernelGGL((wgrad_gang_kernel<5, false>), gr, bl, 5 * WGG_STAGE, st, P);
+        }
         BG_CHECK_LAUNCH("wgrad_gang_kernel");
     }
     return BG_OK;
+}
+
+extern "C" int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, int32_t n_layers, int64_t M, int32_t Cin,
+                                           int32_t Cout, int32_t ldx, int32_t ldy, void* stream) {
+    BG_CHECK_ARG(dtype == BG_BF16, "bg_conv2d_bwd_weight_grouped: bf16 operands only (the transposing LDS reads)");
+    BG_CHECK_ARG(tbl && n_layers >= 1 && M >= 1 && M < (1LL << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 &&
+                 ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, "bg_conv2d_bwd_weight_grouped: bad arguments");
+    // the kernel addresses a layer's operands with 32-bit byte offsets into per-layer descriptors
+    BG_CHECK_ARG((M - 1) * (long long)ldx * 2 + (long long)Cin * 2 < (1LL << 31) && (M - 1) * (long long)ldy * 2 + (long long)Cout * 2 < (1LL << 31),
+                 "bg_conv2d_bwd_weight_grouped: an operand beyond 2 GiB (M=%lld ldx=%d ldy=%d)", (long long)M, ldx, ldy);
+    const WggGeom G{M, 1, 1, (int)M, 1, 1, 1, Cin, Cout, ldx, ldy};
+    return launch_wgrad_gang("bg_conv2d_bwd_weight_grouped", tbl, n_layers, G, stream);
+}
+
+// Weight gradients of n_layers k x k convolutions of ONE geometry (stride 1, odd kernel, "same" padding pad = dil * (k - 1) / 2:
+// the 3x3 convolutions of the decoder and the ASPP) through the gang kernel: tbl rows = (x, dy, dw, 0) as above, dw
+// is [Cout][KH][KW][Cin] fp32, accumulated into.
+extern "C" int bg_conv2d_bwd_weight_grouped_taps(const bg_conv_desc* d, const int64_t* tbl, int32_t n_layers, void* stream) {
+    BG_CHECK_ARG(d && tbl && n_layers >= 1, "bg_conv2d_bwd_weight_grouped_taps: null argument");
+    BG_CHECK_ARG(d->dtype == BG_BF16, "bg_conv2d_bwd_weight_grouped_taps: bf16 operands only (the transposing LDS reads)");
+    BG_CHECK_ARG(d->KH == d->KW && (d->KH & 1) && d->KH >= 1 && d->KH <= 5 && d->stride == 1 && d->dil >= 1 &&
+                 d->pad == d->dil * (d->KH - 1) / 2 && d->Ho == d->H && d->Wo == d->W,
+                 "bg_conv2d_bwd_weight_grouped_taps: stride-1 odd-kernel 'same' convolutions only (k=%d stride=%d pad=%d dil=%d)",
+                 d->KH, d->stride, d->pad, d->dil);
+    const long long M = (long long)d->N * d->H * d->W;
+    BG_CHECK_ARG(M >= 1 && d->Cin >= 8 && d->Cout >= 8 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout &&
+                 d->ldx % 8 == 0 && d->ldy % 8 == 0, "bg_conv2d_bwd_weight_grouped_taps: bad channel counts / pitches");
+    // 32-bit byte offsets, with room for the largest tap shift
+    const long long reach = (long long)d->dil * (d->KH / 2) * ((long long)d->W + 1);
+    BG_CHECK_ARG((M + reach) * (long long)d->ldx * 2 < (1LL << 31) && M * (long long)d->ldy * 2 < (1LL << 31) &&
+                 (long long)d->Cout * d->KH * d->KW * d->Cin * 4 < (1LL << 31),
+                 "bg_conv2d_bwd_weight_grouped_taps: an operand beyond 2 GiB");
+    const WggGeom G{M, d->N, d->H, d->W, d->KH, d->KW, d->dil, d->Cin, d->Cout, d->ldx, d->ldy};
+    return launch_wgrad_gang("bg_conv2d_bwd_weight_grouped_taps", tbl, n_layers, G, stream);
 }
 
 extern "C" int bg_conv_weight_kpad(int32_t dtype) { return dtype_ok(dtype) ? kpad_of(dtype) : BG_E_ARG; }

@@ -167,6 +167,22 @@ def wgrad_group_ok(dtype, kh, kw, stride, pad, dil, has_bias) -> bool:
             and not has_bias)
 
 
+_WG_TAPS_ENABLED = _os.environ.get("BGAMD_WGRAD_TAPS", "1") != "0"
+
+
+def wgrad_taps_ok(dtype, n, h, w, cin, cout, kh, kw, stride, pad, dil, has_bias, ldx, ldy) -> bool:
+    """k x k stride-1 'same' convolutions whose weight gradient goes through the gang kernel (bg_conv2d_bwd_weight_grouped_taps):
+    measured (scripts/bench_wgrad.py) 1.3-1.9x the per-layer kernel on the decoder's and the ASPP's 3 x 3 layers; layers
+    whose 256 x 256 tiles would be mostly padding, or whose maps are too small to give every gang a long range, stay."""
+    if not (_WG_GROUP_ENABLED and _WG_TAPS_ENABLED and dtype == torch.bfloat16 and kh == kw and kh in (3, 5) and stride == 1
+            and pad == dil * (kh - 1) // 2 and not has_bias and _gang_shape_ok(cin, cout, 0.55)):
+        return False
+    rows = n * h * w
+    if (rows + dil * (kh // 2) * (w + 1)) * max(ldx, ldy) * 2 >= (1 << 31) or cout * kh * kw * cin * 4 >= (1 << 31):
+        return False            # the gang kernel's 32-bit operand offsets
+    return rows * kh * kw >= 64 * 256           # >= 64 K-steps (of 32 pixels) per workgroup
+
+
 def wgrad_group_add(dev, x, g, dw_ptr, rows, cin, cout, desc):
     """Queue dW += g^T x of one pointwise layer for the end-of-backward grouped launch."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -187,18 +203,21 @@ def wgrad_group_add(dev, x, g, dw_ptr, rows, cin, cout, desc):
         wgrad_group_flush(key, sig)
 
 
-def _gang_pays(n_layers, cin, cout) -> bool:
-    """Measured (scripts/bench_wgrad.py): the gang launch beats the per-layer kernel for groups of layers (1.6-2.0x on
-    the 48 middle-flow layers) and for single layers with many output tiles (1536 x 1536 and up: 1.1-1.3x); a single
-    layer of up to 12 tiles is 0.7-0.9x (one range per gang is too short against its flush)."""
+def _gang_pays(n_layers, cin, cout, rows=0) -> bool:
+    """Measured (scripts/bench_wgrad.py): the gang launch beats the per-layer kernel for groups of layers (3.0x on the 48
+    middle-flow layers), for single layers with many output tiles (1536 x 1536 and up: 1.3-1.6x) and for single layers
+    whose pixel count gives every gang a long range (728 -> 728 at 144 x 96: 1.5x); a single layer of up to 12 tiles
+    on few pixels is 0.9x (one range per gang is too short against its flush)."""
     tiles = (-(-cin // 256)) * (-(-cout // 256))
-    return _gang_shape_ok(cin, cout) and (n_layers >= 2 or tiles >= 24)
+    long_ranges = rows // 32 >= 96 * max(1, 256 // tiles) and tiles >= 2
+    return _gang_shape_ok(cin, cout) and (n_layers >= 2 or tiles >= 24 or long_ranges)
 
 
-def _gang_shape_ok(cin, cout) -> bool:
-    """256 x 256 tiles mostly padding (128-channel layers): 0.3-0.5x of the per-layer kernel, whatever the group size."""
+def _gang_shape_ok(cin, cout, fill=0.7) -> bool:
+    """256 x 256 tiles mostly padding (128-channel layers): 0.3-0.5x of the per-layer kernel, whatever the group size.
+    (k x k layers: 304 -> 256, 59 % filled, is still 1.45x.)"""
     tiles = (-(-cin // 256)) * (-(-cout // 256))
-    return cin * cout >= 0.7 * tiles * 65536
+    return cin * cout >= fill * tiles * 65536
 
 
 def wgrad_group_flush(key, only_sig=None):
@@ -223,7 +242,7 @@ def wgrad_group_flush(key, only_sig=None):
             for x, g, _, _ in jobs:
                 x.record_stream(side)
                 g.record_stream(side)
-        if not _gang_pays(len(jobs), cin, cout):
+        if not _gang_pays(len(jobs), cin, cout, rows):
             for x, g, dwp, desc in jobs:
                 if use_side:
                     L.call_on(raw, "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dwp, None)
@@ -520,6 +539,11 @@ class Conv2dFn(torch.autograd.Function):
                 dbias = arena.grad_ptr(bslot)
             if wgrad_group_ok(xdtype, kh, kw, stride, pad, dil, dbias is not None) and x.shape[3] == cin and g.shape[3] == kp:
                 wgrad_group_add(xdev, x, g, arena.grad_ptr(wslot), n * h * w, cin, kp, desc)
+            elif wgrad_taps_ok(xdtype, n, h, w, cin, kp, kh, kw, stride, pad, dil, dbias is not None, ld_of(x), ld_of(g)):
+                # a k x k layer as k*k pointwise weight gradients against shifted x in the gang kernel; issued at once (a
+                # single layer: nothing to group), on the side stream.  The one-row table is host memory read during the call.
+                tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), 0]], dtype=torch.int64)
+                wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)
             else:
                 wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
         return dx, None, None, None, None, None, None, None, None, None

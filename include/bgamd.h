@@ -112,6 +112,12 @@ int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, f
  * than ranges' worth of work (then the result is bit-reproducible), operands are read from HBM once.  No bias. */
 int bg_conv2d_bwd_weight_grouped(int32_t dtype, const int64_t* tbl, int32_t n_layers, int64_t M, int32_t Cin, int32_t Cout,
                                  int32_t ldx, int32_t ldy, void* stream);
+/* The same for n_layers k x k convolutions of ONE geometry d (bf16; stride 1, odd square kernel <= 5, pad = dil*(k-1)/2,
+ * so Ho = H, Wo = W: the 3x3 convolutions of the decoder, deeplab.py:363-369, and of the ASPP, :331): a tap is a
+ * pointwise weight gradient against x shifted by the tap's rows / columns with the border masked, so the nine taps
+ * run as members of one gang (few tiles: dy and the shifted windows of x are fetched once per XCD) or as nine layers.
+ * dw_l is [Cout][KH][KW][Cin] fp32, accumulated into; tbl as above. */
+int bg_conv2d_bwd_weight_grouped_taps(const bg_conv_desc* d, const int64_t* tbl, int32_t n_layers, void* stream);
 
 /* Reduction-dimension padding granule of the packed weight copies (elements). */
 int bg_conv_weight_kpad(int32_t dtype);

@@ -37,3 +37,29 @@ for nl, m, cin, cout in CASES[:int(os.environ.get('CASES_ONLY', len(CASES)))]:
     a, b = min(res["per-layer"]), min(res["grouped"])
     print(f"{nl:2d} x [{m:7d} px, {cin:4d} -> {cout:4d}]: per-layer {a:9.1f} us {flops / a * 1e-6:6.0f} TF | grouped {b:9.1f} us "
           f"{flops / b * 1e-6:6.0f} TF | x{a / b:.2f}", flush=True)
+
+
+# k x k layers: per-layer kernel against the gang kernel with the taps as gang members / layers
+KK = [(8, 288, 192, 256, 256, 3, 1), (8, 288, 192, 304, 256, 3, 1), (16, 288, 192, 256, 256, 3, 1), (8, 72, 48, 2048, 256, 3, 12),
+      (8, 72, 48, 2048, 256, 3, 6), (8, 144, 96, 256, 256, 3, 1), (8, 72, 48, 728, 728, 3, 1), (2, 64, 64, 256, 256, 3, 1)]
+for n, h, w, cin, cout, k, dil in (KK if not os.environ.get("CASES_ONLY") else KK[:int(os.environ["CASES_ONLY"])]):
+    x = torch.randn(n, h, w, cin, device="cuda").bfloat16()
+    g = (torch.randn(n, h, w, cout, device="cuda") * 0.01).bfloat16()
+    dw = torch.zeros(cout, k, k, cin, device="cuda")
+    desc = L.ConvDesc(L.BF16, n, h, w, cin, h, w, cout, k, k, 1, dil * (k - 1) // 2, dil, cin, cout)
+    tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), dw.data_ptr(), 0]], dtype=torch.int64)
+    flops = 2.0 * n * h * w * cin * cout * k * k
+    fns = (("per-layer", lambda: L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dw.data_ptr(), None)),
+           ("gang", lambda: L.call("bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)))
+    res = {}
+    for rnd in range(3):
+        for name, fn in fns:
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3): fn()
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(name, []).append(e0.elapsed_time(e1) / 3 * 1e3)
+    a, b = min(res["per-layer"]), min(res["gang"])
+    print(f"{k}x{k} d{dil:2d} [{n:2d} x {h:3d} x {w:3d}, {cin:4d} -> {cout:4d}]: per-layer {a:9.1f} us {flops / a * 1e-6:6.0f} TF | gang {b:9.1f} us "
+          f"{flops / b * 1e-6:6.0f} TF | x{a / b:.2f}", flush=True)

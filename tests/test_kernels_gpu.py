@@ -657,6 +657,54 @@ def test_conv_wgrad_grouped(case):
             assert torch.equal(a, b), "grouped weight gradient is not bit-reproducible"
 
 
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, dil, slack, layers
+    (2, 24, 40, 256, 256, 3, 1, 0, 1),       # nine taps as members of one gang (T = 9)
+    (1, 37, 33, 304, 256, 3, 1, 8, 1),       # two ci tiles (T = 18), ragged map: 1221 pixels, W not a multiple of anything
+    (2, 20, 24, 512, 256, 3, 6, 0, 1),       # dilation 6: most of the border masked
+    (1, 16, 20, 1024, 256, 3, 12, 0, 2),     # 4 tiles x 9 taps > 32: taps as layers; dilation beyond half the map; 2 layers
+    (3, 12, 20, 256, 512, 3, 2, 0, 1),       # W < 32: several rows per K-step; images change inside a K-step
+    (1, 40, 48, 256, 256, 5, 1, 0, 1),       # 5 x 5: 25 taps
+])
+def test_conv_wgrad_grouped_taps(case):
+    """bg_conv2d_bwd_weight_grouped_taps: the weight gradient of k x k stride-1 'same' convolutions through the gang
+    kernel (a tap = a pointwise weight gradient against x shifted by the tap's rows / columns, border masked), against
+    torch's fp32 convolution weight gradient of the same bf16-representable operands and against the per-layer kernel;
+    accumulation semantics."""
+    n, h, w, cin, cout, k, dil, slack, nl = case
+    dtype = torch.bfloat16
+    g_ = torch.Generator(device=DEV).manual_seed(11)
+    ldx, ldy = cin + slack, cout + slack
+    pad = dil * (k - 1) // 2
+    xs = [torch.randn((n, h, w, ldx), generator=g_, device=DEV).to(dtype) for _ in range(nl)]
+    gs = [(torch.randn((n, h, w, ldy), generator=g_, device=DEV) / math.sqrt(n * h * w)).to(dtype) for _ in range(nl)]
+    dws = [torch.full((cout, k, k, cin), 0.25, device=DEV) for _ in range(nl)]
+    desc = L.ConvDesc(L.BF16, n, h, w, cin, h, w, cout, k, k, 1, pad, dil, ldx, ldy)
+    tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), d.data_ptr(), 0] for x, g, d in zip(xs, gs, dws)], dtype=torch.int64)
+    L.call("bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), nl)
+    for l in range(nl):
+        xn = xs[l][..., :cin].float().permute(0, 3, 1, 2).contiguous()
+        gn = gs[l][..., :cout].float().permute(0, 3, 1, 2).contiguous()
+        ref = torch.nn.grad.conv2d_weight(xn, (cout, cin, k, k), gn, stride=1, padding=pad, dilation=dil)   # [co][ci][r][s]
+        assert_close((dws[l] - 0.25).cpu(), ref.permute(0, 2, 3, 1).contiguous().cpu(), 2e-3, f"layer {l}")
+    dw1 = torch.zeros(cout, k, k, cin, device=DEV)
+    L.call("bg_conv2d_bwd_weight", desc, xs[0].data_ptr(), gs[0].data_ptr(), dw1.data_ptr(), None)
+    assert_close((dws[0] - 0.25).cpu(), dw1.cpu(), 1e-4, "gang vs per-layer")
+    first = dws[0].clone()
+    L.call("bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), nl)
+    assert_close((dws[0] - 0.25).cpu(), 2 * (first - 0.25).cpu(), 1e-5, "accumulate")
+
+
+def test_conv_wgrad_grouped_taps_rejects_other_geometries():
+    x = torch.zeros(1, 8, 8, 256, device=DEV, dtype=torch.bfloat16)
+    dw = torch.zeros(256, 3, 3, 256, device=DEV)
+    tbl = torch.tensor([[x.data_ptr(), x.data_ptr(), dw.data_ptr(), 0]], dtype=torch.int64)
+    for kw in (dict(stride=2, pad=1, ho=4), dict(stride=1, pad=0, ho=6)):
+        d = L.ConvDesc(L.BF16, 1, 8, 8, 256, kw["ho"], kw["ho"], 256, 3, 3, kw["stride"], kw["pad"], 1, 256, 256)
+        with pytest.raises(RuntimeError, match="stride-1 odd-kernel"):
+            L.call("bg_conv2d_bwd_weight_grouped_taps", d, tbl.data_ptr(), 1)
+
+
 def test_conv_operands_beyond_2gib():
     """Activations larger than 2 GiB (the 2304x1536x32 configuration's entry flow at batch 16): the fat-tile kernel rebases
     its buffer descriptors per tile, so 32-bit offsets never span the tensor.  Sampled pixels (first, around the 2 GiB
