@@ -494,6 +494,7 @@ __global__ __launch_bounds__(TCH * TP / 64) void gemm_conv_dma_kernel(GemmConvPa
     if (KT > 1) issue(1);
     if (DIST > 2 && KT > 2) issue(2);
     int buf = 0, nbuf = DIST % NBUF;
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // compiler-visible lgkmcnt(0): see gemm_conv_fat_kernel (counted LDS waits inside the loop)
     for (int kt = 0; kt < KT; ++kt) {
         // retire this wave's DMAs of step kt (leave the later steps' in flight), then meet the others
         const int ahead = KT - 1 - kt;  // steps issued beyond kt, capped by DIST-1

@@ -631,6 +631,10 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
     const int r16 = lane & 15, q = lane >> 4;
     const int rowA = wave_c * MI * 16, rowB = wave_p * NJ * 16;
     int buf = 0, nbuf = DIST % NBUF;
+    // A real s_waitcnt lgkmcnt(0) the compiler can SEE (encoding: vmcnt 63, expcnt 7, lgkmcnt 0): a scalar load still pending on
+    // the loop's entry edge makes its waitcnt pass treat lgkmcnt as out-of-order at the loop header, and then the first LDS
+    // wait of EVERY iteration is lgkmcnt(0) -- all nine fragment reads before the first MFMA -- instead of a count.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     for (int kt = 0; kt < KT; ++kt) {
 #ifdef BG_STAMPS
         if (kt == 1) { BG_STAMP(2); BG_STAMP_CYC(6); }
@@ -687,18 +691,31 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
         } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < BKB / 64; ++ks) {
+                // the A fragment first, then the B fragments in the order the MFMAs take them: the LDS returns in order, so
+                // the first MFMA waits for two reads instead of all eight (both waves of a SIMD stand here right after the
+                // step's barrier with nothing else to issue)
+                // (the first group's pieces go out BEFORE the reads: a branch between the reads and their MFMAs made the
+                // compiler's waitcnt pass fall back to lgkmcnt(0))
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+#pragma unroll
+                    for (int e = 0; e < PPG; ++e)
+                        if (ks * MI * PPG + e < GROUP) piece(nbuf, ks * MI * PPG + e);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 bf16x8 b[NJ];
+#ifndef ABL_FAT_NO_A
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + r16, ks * 4 + q));
+#endif
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q));
 #ifdef ABL_FAT_NO_A
                 bf16x8 a = b[0];
-#else
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + r16, ks * 4 + q));
 #endif
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) {
+                    if (more && i > 0) {
 #pragma unroll
                         for (int e = 0; e < PPG; ++e)
                             if ((ks * MI + i) * PPG + e < GROUP) piece(nbuf, (ks * MI + i) * PPG + e);
