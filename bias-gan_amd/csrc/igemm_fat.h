@@ -689,46 +689,58 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
                 a = an;
             }
         } else if constexpr (sizeof(T) == 2) {
+            // The fragments of K-substep ks + 1 are read during the LAST MFMA group of substep ks -- the A fragment as that
+            // group's look-ahead read, each B fragment right after the MFMA that took its predecessor (same registers) -- so
+            // a substep starts with its operands in flight instead of with nine reads and an idle matrix pipe.  The first
+            // substep's reads stand behind the step's barrier: the A fragment first, then the B fragments in the order
+            // the MFMAs take them (the LDS returns in order: the first MFMA waits for two reads, not nine); the first group's
+            // pieces go out BEFORE the reads (a branch between the reads and their MFMAs cost the counted waits).
+            constexpr int NKS = BKB / 64;
+            auto rd_a = [&](int i, int ks) { return *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + i * 16 + r16, ks * 4 + q)); };
+            auto rd_b = [&](int j, int ks) { return *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q)); };
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
 #pragma unroll
-            for (int ks = 0; ks < BKB / 64; ++ks) {
-                // the A fragment first, then the B fragments in the order the MFMAs take them: the LDS returns in order, so
-                // the first MFMA waits for two reads instead of all eight (both waves of a SIMD stand here right after the
-                // step's barrier with nothing else to issue)
-                // (the first group's pieces go out BEFORE the reads: a branch between the reads and their MFMAs made the
-                // compiler's waitcnt pass fall back to lgkmcnt(0))
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-#pragma unroll
-                    for (int e = 0; e < PPG; ++e)
-                        if (ks * MI * PPG + e < GROUP) piece(nbuf, ks * MI * PPG + e);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 b[NJ];
-#ifndef ABL_FAT_NO_A
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + r16, ks * 4 + q));
+                for (int e = 0; e < PPG; ++e)
+                    if (e < GROUP) piece(nbuf, e);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 b[NJ];
+#ifndef ABL_FAT_NO_A   // ablation (scripts/ablate_fat.sh): no A fragment reads
+            bf16x8 a = rd_a(0, 0);
 #endif
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<BKB>(rowB + j * 16 + r16, ks * 4 + q));
+            for (int j = 0; j < NJ; ++j) b[j] = rd_b(j, 0);
 #ifdef ABL_FAT_NO_A
-                bf16x8 a = b[0];
+            bf16x8 a = b[0];
 #endif
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more && i > 0) {
+                    if (more && ks * MI + i > 0) {
 #pragma unroll
                         for (int e = 0; e < PPG; ++e)
                             if ((ks * MI + i) * PPG + e < GROUP) piece(nbuf, (ks * MI + i) * PPG + e);
                     }
+                    const bool carry = i == MI - 1 && ks + 1 < NKS;     // this group hands over to the next substep
                     bf16x8 an = a;
 #ifdef ABL_FAT_NO_A
-                    if (i + 1 < MI) an = b[(i + 1) % NJ];
+                    an = b[(i + 1) % NJ];
 #else
-                    if (i + 1 < MI) an = *reinterpret_cast<const bf16x8*>(sA + lds_off<BKB>(rowA + (i + 1) * 16 + r16, ks * 4 + q));
+                    if (i + 1 < MI) an = rd_a(i + 1, ks);
+                    else if (carry) an = rd_a(0, ks + 1);
 #endif
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+                        if (carry) {
+                            __builtin_amdgcn_sched_barrier(0);      // the read may not move above the MFMA that frees its registers
+                            b[j] = rd_b(j, ks + 1);
+                        }
+                    }
                     __builtin_amdgcn_s_setprio(0);
                     a = an;
                 }
