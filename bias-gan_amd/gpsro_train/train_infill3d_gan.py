@@ -66,7 +66,128 @@ class InfillGANTrainer:
 
     def step(self, inputs_raw, outputs_real, masks_raw, noise, labels=None, comm=None):
         """inputs_raw, outputs_real, masks_raw: [N,1,D,H,W] fp32 on the device; noise [N,nd,D,H,W] (the reference draws
-        it on the host and copies it over).  Returns (d_loss, g_loss) as device scalars."""
+        it on the host and copies it over).  Returns (d_loss, g_loss) as device scalars.
+
+        Where the iteration qualifies (_graph_ok) it is captured into ONE hipGraph per (shapes, update flags, warm-up)
+        configuration on its third call and replayed afterwards: its ~580 launches against ~12 ms of kernels made it
+        host-bound.  The update flags are picked on the host, from last iteration's accuracy, BEFORE the graph is chosen."""
+        if self._graph_ok(inputs_raw, comm):
+            return self._graph_step(inputs_raw, outputs_real, masks_raw, noise, labels)
+        return self._eager_step(inputs_raw, outputs_real, masks_raw, noise, labels, comm)
+
+    # -- whole-step hipGraph (the machinery of gpsro_train.train_gan.GANTrainer._graph_step) ---------------------------
+    def _graph_ok(self, inputs_raw, comm):
+        import os
+        from .. import _lib as L
+        if os.environ.get("BGAMD_STEP_GRAPH") == "0" or L.PROFILE is not None or not inputs_raw.is_cuda:
+            return False
+        if torch.cuda.is_current_stream_capturing() or (comm is not None and comm.size() > 1):
+            return False
+        if isinstance(self.generator, DistributedModel) or isinstance(self.discriminator, DistributedModel):
+            return False
+        if getattr(self.criterion_gan, "mode", None) != "ModifiedMinMax":
+            return False
+        return type(self.g_opt).__name__ == "FusedAdam" and type(self.d_opt).__name__ == "FusedAdam"
+
+    def _graph_step(self, inputs_raw, outputs_real, masks_raw, noise, labels):
+        train_g, train_d = self.update_flags()
+        def _opt_key(o):
+            return tuple((float(g["eps"]), float(g["weight_decay"]), tuple(float(b) for b in g["betas"]),
+                          bool(g.get("amsgrad", False)), type(o).__name__ + str(g.get("decoupled", ""))) for g in o.param_groups)
+        key = (tuple(inputs_raw.shape), tuple(noise.shape), inputs_raw.dtype, train_g, train_d, self.step_count < self.warmup,
+               id(getattr(_unwrap(self.generator), "_bg_arena", None)), id(getattr(_unwrap(self.discriminator), "_bg_arena", None)),
+               tuple(sorted(self.loss_weights.items())), id(self.criterion_gan), id(self.criterion_reconst),
+               _opt_key(self.d_opt), _opt_key(self.g_opt))
+        if not hasattr(self, "_graphs"):
+            self._graphs, self._graph_seen, self._graph_failed = {}, {}, set()
+        e = self._graphs.get(key)
+        if key in self._graph_failed or (e is None and self._graph_seen.get(key, 0) < 2):   # two eager steps first
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            return self._eager_step(inputs_raw, outputs_real, masks_raw, noise, labels, None)
+        # the host's random draws, in the eager order; a swap exchanges the two label tensors -- no branch in the graph
+        lf, lr_, swap = labels if labels is not None else self.criterion_gan.draw_labels()
+        lab = (lr_, lf) if swap else (lf, lr_)
+        dev = inputs_raw.device
+        srcs = (inputs_raw, outputs_real, masks_raw, noise)
+        if e is None:
+            e = {"in": tuple(t.clone() for t in srcs), "lab": tuple(t.to(dev).clone() for t in lab)}
+        else:
+            for dst, src in zip(e["in"], srcs):
+                dst.copy_(src, non_blocking=True)
+            for dst, src in zip(e["lab"], lab):
+                dst.copy_(src if src.is_cuda else src.pin_memory(), non_blocking=True)
+        opts = ([self.d_opt] if train_d else []) + ([self.g_opt] if train_g else [])
+        pool = StatsPool.get(dev)
+        if "graph" not in e:
+            t_before = [o._t for o in opts]
+            for o in opts:
+                o.prepare_replay()
+            try:
+                self._capture(e, key, opts, pool)
+            except Exception as err:   # noqa: BLE001 -- whatever the capture raised, the eager path is the fallback
+                for o, t in zip(opts, t_before):
+                    o._t = t
+                self._graph_failed.add(key)
+                self._graphs.pop(key, None)
+                import warnings
+                warnings.warn(f"whole-step hipGraph capture failed ({type(err).__name__}: {err}); this configuration stays eager")
+                torch.cuda.synchronize()
+                return self._eager_step(inputs_raw, outputs_real, masks_raw, noise, labels, None)
+        else:
+            for o in opts:
+                o.prepare_replay()       # step count, lr and bias corrections of THIS step -> device
+            for net in (self.generator, self.discriminator):
+                _unwrap(net).arena().sync()     # weights written outside the graph since the last step
+            pool.used = e["pool_after"]
+            for m_, k in e["nbt"]:
+                m_.__dict__["_bg_nbt_pending"] = m_.__dict__.get("_bg_nbt_pending", 0) + k
+            e["graph"].replay()
+            if train_d and self.d_scheduler is not None:
+                self.d_scheduler.step()
+            if train_g and self.g_scheduler is not None:
+                self.g_scheduler.step()
+            self.step_count += 1
+        self.last_flags = (train_g, train_d)
+        self.last_terms = e["terms"]
+        self._publish_accuracy(e["acc"])
+        return e["d_loss"], e["g_loss"]
+
+    def _capture(self, e, key, opts, pool):
+        import torch.nn as nn
+        bns = [m for net in (self.generator, self.discriminator) for m in _unwrap(net).modules()
+               if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        before = [m.__dict__.get("_bg_nbt_pending", 0) for m in bns]
+        for net in (self.generator, self.discriminator):       # packed weight copies current before the graph starts
+            _unwrap(net).arena().sync()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        for o in opts:
+            o.capturing = True
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g):
+                d_loss, g_loss = self._eager_step(*e["in"], (e["lab"][0], e["lab"][1], False), None)
+        finally:
+            self._capturing = False
+            for o in opts:
+                o.capturing = False
+        e.update(graph=g, d_loss=d_loss, g_loss=g_loss, acc=self._acc_dev, terms=self.last_terms, pool_after=pool.used,
+                 nbt=[(m, m.__dict__.get("_bg_nbt_pending", 0) - b) for m, b in zip(bns, before) if m.__dict__.get("_bg_nbt_pending", 0) != b])
+        self._graphs[key] = e
+        g.replay()                      # capture records, it does not execute
+
+    def _publish_accuracy(self, acc):
+        """The accuracy steers the NEXT iteration: asynchronous read-back into pinned memory (see d_acc_avg)."""
+        if acc.is_cuda:
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host.copy_(acc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._acc_pending = (host, ev, 1.0)
+        else:
+            self._d_acc = float(acc)
+
+    def _eager_step(self, inputs_raw, outputs_real, masks_raw, noise, labels=None, comm=None):
         StatsPool.reset_all()
         inputs = torch.cat((inputs_raw, noise), dim=1)
         masks = torch.cat((masks_raw, torch.ones_like(noise)), dim=1)
@@ -84,14 +205,10 @@ class InfillGANTrainer:
             import torch.distributed as dist
             acc = acc.clone()
             dist.all_reduce(acc)
-        if acc.is_cuda:
-            host = torch.empty((), dtype=torch.float32, pin_memory=True)
-            host.copy_(acc, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._acc_pending = (host, ev, 1.0)
+        if getattr(self, "_capturing", False):
+            self._acc_dev = acc          # read back after every replay (_graph_step)
         else:
-            self._d_acc = float(acc)
+            self._publish_accuracy(acc)
         if train_d:
             self.d_opt.zero_grad()
             d_loss.backward()

@@ -24,10 +24,10 @@ for (n, d, h, w) in ((4, 45, 19, 37), (16, 45, 19, 37), (4, 64, 96, 96), (4, 45,
     gt = torch.randn(n, 1, d, h, w, device=dev)
     mask = (torch.rand(n, 1, d, h, w, device=dev) > 0.3).float()
     x, noise = gt * mask, torch.randn(n, 1, d, h, w, device=dev)
-    for _ in range(2):
+    for _ in range(4):      # two eager steps, the capture, one replay
         tr.step(x, gt, mask, noise)
     torch.cuda.synchronize()
-    steps = 5
+    steps = 10
     t0 = time.perf_counter()
     for _ in range(steps):
         dl, gl = tr.step(x, gt, mask, noise)

@@ -277,6 +277,51 @@ def test_infill_gan_loop_vs_reference_trajectory(golden_dir):
         assert int(D.state_dict()["enc_2.bn.num_batches_tracked"]) == 3 * (s + 1)
 
 
+def test_infill_trainer_whole_step_graph_matches_eager(monkeypatch):
+    """InfillGANTrainer.step captured into one hipGraph per (update flags, warm-up) configuration and replayed (the
+    iteration's ~580 launches against ~12 ms of kernels made it host-bound), against the eager loop on the same seeds and
+    labels.  With the learning rate at 0 every iteration's losses depend on that iteration's inputs only and must agree to
+    rounding; the update flags (from the previous iteration's accuracy, read back after each replay), the accuracies and
+    the host-side counters must follow the eager run's."""
+    from bias_gan_amd.gpsro_train.train_infill3d_gan import InfillGANTrainer
+    from bias_gan_amd.utils import losses
+    from bias_gan_amd.utils import parsing_helpers as ph
+    n, nd, d, h, w = 2, 1, 32, 24, 40      # the golden trajectory's geometry (the critic's head is sized by it)
+    gl, dl = 4, 5
+
+    def run(flag):
+        monkeypatch.setenv("BGAMD_STEP_GRAPH", flag)
+        G = ig.Generator(layer_size=gl, input_channels=1 + nd, output_channels=1, normalizer=nn.BatchNorm3d, compute_dtype=F32)
+        D = ig.Discriminator(layer_size=dl, input_channels=1 + nd, normalizer=nn.BatchNorm3d, compute_dtype=F32)
+        G.load_state_dict(oi.fill_state(oi.unet3d_spec(1 + nd, 1, gl), 71))
+        D.load_state_dict(oi.fill_state(oi.disc3d_spec(1 + nd, dl), 72))
+        G.to(DEV).train(), D.to(DEV).train()
+        tr = InfillGANTrainer(G, D, ph.get_optimizer(G.parameters(), "AdamW", 0.0, 1e-8, 0.0), ph.get_optimizer(D.parameters(), "AdamW", 0.0, 1e-8, 0.0),
+                              losses.GANLoss("ModifiedMinMax", n, torch.device(DEV)), ig.InpaintingLoss("l1"),
+                              {"hole": 6.0, "valid": 1.0, "tv": 0.1, "adv": 0.1}, 2, 0.3, 0.9)
+        out = []
+        for s_ in range(9):
+            torch.manual_seed(700 + s_)      # the label draw
+            x, gt, mask = oi.synthetic_infill(n, 1, d, h, w, 300 + s_)
+            noise = torch.randn((n, nd, d, h, w), generator=torch.Generator().manual_seed(400 + s_))
+            d_loss, g_loss = tr.step(x.to(DEV), gt.to(DEV), mask.to(DEV), noise.to(DEV))
+            out.append((float(d_loss), float(g_loss), tr.last_flags, round(tr.d_acc_avg, 6), {k: float(v) for k, v in tr.last_terms.items()}))
+        torch.cuda.synchronize()
+        nbt = int(G.state_dict()["enc_2.bn.num_batches_tracked"]), int(D.state_dict()["enc_2.bn.num_batches_tracked"])
+        return out, len(getattr(tr, "_graphs", {})), (tr.g_opt._t, tr.d_opt._t, tr.step_count, nbt)
+
+    (e, ge, ce), (g, gg, cg) = run("0"), run("1")
+    assert ge == 0 and gg >= 1
+    assert ce == cg, (ce, cg)
+    for i, (a, b) in enumerate(zip(e, g)):
+        print(f"step {i}: eager d {a[0]:.6f} g {a[1]:.6f} flags {a[2]} acc {a[3]} | graph d {b[0]:.6f} g {b[1]:.6f} flags {b[2]} acc {b[3]}")
+        assert a[2:4] == b[2:4], (i, a, b)
+        assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]) + 1e-6, (i, a, b)
+        assert a[4].keys() == b[4].keys()
+        for k in a[4]:
+            assert abs(a[4][k] - b[4][k]) <= 2e-5 * abs(a[4][k]) + 1e-6, (i, k, a[4][k], b[4][k])
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_unet2d_vs_reference_golden(golden_dir, dtype):
     """2-D PConvUNet / PartialConv2d (SURVEY 8(f)-4 "2-D shapes"): the planar mask window, masks bit-exact, the
