@@ -656,6 +656,12 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
             // is order-independent), so a lane takes chunks q and 4 + q -- the two ds_read_b128 of the bf16 loop's two
             // K-substeps, conflict-free under the same swizzle.
             static_assert(BKB == 128, "fp8: 128-byte rows = one MFMA K");
+            auto load_a = [&](int i) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(sA + lds_off<BKB>(rowA + i * 16 + r16, q));
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(sA + lds_off<BKB>(rowA + i * 16 + r16, 4 + q));
+                return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            i32x8 a = load_a(0);        // the A fragment first: the first MFMA then waits for four reads, not sixteen (bf16 path below)
             i32x8 b[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -663,12 +669,6 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
                 const i32x4 hi = *reinterpret_cast<const i32x4*>(sB + lds_off<BKB>(rowB + j * 16 + r16, 4 + q));
                 b[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            auto load_a = [&](int i) {
-                const i32x4 lo = *reinterpret_cast<const i32x4*>(sA + lds_off<BKB>(rowA + i * 16 + r16, q));
-                const i32x4 hi = *reinterpret_cast<const i32x4*>(sA + lds_off<BKB>(rowA + i * 16 + r16, 4 + q));
-                return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            };
-            i32x8 a = load_a(0);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 __builtin_amdgcn_sched_barrier(0);
