@@ -132,6 +132,19 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Workgroup barrier for data exchanged through the LDS only: waits for this wave's LDS traffic, not for its global
+// stores (__syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: behind a tile's output stores it makes the
+// workgroup wait until they have been acknowledged).  Used in the statistics exchange of the epilogues.  Measured: no
+// change on the HBM-bound 128 / 256-channel layers, whose statistics epilogue costs 18-30 us per launch over the plain
+// forward (scripts/bench_fat.py, WITH_PLAIN_FWD=1) -- nor is it the fp64 atomics (an ablation without them costs the
+// same): with two workgroups per CU, the ~400 instructions and two barriers of the reduction are time in which the
+// workgroup has no loads in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Geometry of the epilogue's transposition buffer: one 16-pixel x (MI*16-channel) block per wave, UNPADDED rows of
 // CHB bytes, bank-conflict free on both sides (scripts/lds_conflicts.py, the LDS model of MI355X_MICROARCH.md):
 //   writer  lane (pixel r16, channel quad q) stores its 4 channels of fragment i (8 B bf16: ds_write_b64, serviced in
@@ -267,7 +280,7 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
                     red[(wave_p * TM + cl) * 2 + 1] = s2[i][e];
                 }
         }
-        __syncthreads();
+        lds_barrier();     // NOT __syncthreads(): its vmcnt(0) would wait for the tile's stores to be acknowledged
         const int t = threadIdx.x;
         if (t < TM && c_base + t < P.NO) {
             const long long o = (long long)grp * P.NO + c_base + t;
@@ -401,7 +414,7 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
                     red[(wave_p * TM + cl) * 2 + 1] = s2[i][e];
                 }
         }
-        __syncthreads();
+        lds_barrier();     // NOT __syncthreads(): its vmcnt(0) would wait for the tile's stores to be acknowledged
         const int t = threadIdx.x;
         if (t < TM && c_base + t < P.NO) {
             const long long o = (long long)grp * P.NO + c_base + t;

@@ -15,6 +15,8 @@ SHAPES = [  # cin, cout, k, dil, H, W
     (128, 128, 1, 1, 576, 384), (128, 128, 3, 1, 576, 384), (128, 128, 1, 1, 288, 192), (128, 256, 1, 1, 288, 192),
     (128, 48, 1, 1, 288, 192),
 ]
+if os.environ.get("SHAPES") == "hbm":
+    SHAPES = [s_ for s_ in SHAPES if s_[0] <= 256 and s_[2] == 1]
 if os.environ.get("SHAPES") == "small":
     SHAPES = [s_ for s_ in SHAPES if s_[1] <= 128 or s_[0] == 728 and s_[4] == 72]
 batches = [int(a) for a in sys.argv[1:]] or [8, 16]
@@ -36,6 +38,8 @@ for N in batches:
         fns = (("fwd_stats", lambda: L.call("bg_conv2d_fwd_stats", desc, x.data_ptr(), w.data_ptr(), y.data_ptr(),
                                             st[0].data_ptr(), st[1].data_ptr(), 1)),
                ("dgrad    ", lambda: L.call("bg_conv2d_bwd_data", desc, dy.data_ptr(), wt.data_ptr(), dx.data_ptr())))
+        if os.environ.get("WITH_PLAIN_FWD"):     # the forward pass without its statistics epilogue
+            fns += (("fwd      ", lambda: L.call("bg_conv2d_fwd", desc, x.data_ptr(), w.data_ptr(), None, y.data_ptr())),)
         for name, fn in fns:
             res = {}
             for rnd in range(3):
