@@ -135,10 +135,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Workgroup barrier for data exchanged through the LDS only: waits for this wave's LDS traffic, not for its global
 // stores (__syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: behind a tile's output stores it makes the
 // workgroup wait until they have been acknowledged).  Used in the statistics exchange of the epilogues.  Measured: no
-// change on the HBM-bound 128 / 256-channel layers, whose statistics epilogue costs 18-30 us per launch over the plain
-// forward (scripts/bench_fat.py, WITH_PLAIN_FWD=1) -- nor is it the fp64 atomics (an ablation without them costs the
-// same): with two workgroups per CU, the ~400 instructions and two barriers of the reduction are time in which the
-// workgroup has no loads in flight.
+// change by itself on the HBM-bound 128 / 256-channel layers, whose statistics epilogue costs 18-30 us per launch over
+// the plain forward (scripts/bench_fat.py, WITH_PLAIN_FWD=1).  The ablation build -DABL_STAT_NOATOM splits that cost:
+// 8-18 us are the fp64 atomics (1 728 - 6 912 tiles adding into the same 2 x Cout addresses), 4-20 us the reduction's
+// ~400 instructions and two barriers, during which a workgroup (two per CU) has no loads in flight.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -290,8 +290,12 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
                 a1 += red[(wp * TM + t) * 2];
                 a2 += red[(wp * TM + t) * 2 + 1];
             }
+#ifdef ABL_STAT_NOATOM   // ablation (scripts/bench_fat.py): the whole reduction, no atomics (a never-taken store keeps it alive)
+            if (a1 == 12345.678f && a2 == 0.f) P.stat_sum[o] = 1.0;
+#else
             atomicAdd(P.stat_sum + o, (double)a1);
             atomicAdd(P.stat_sq + o, (double)a2);
+#endif
         }
     }
 }
@@ -424,8 +428,12 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
                 a1 += red[(wp * TM + t) * 2];
                 a2 += red[(wp * TM + t) * 2 + 1];
             }
+#ifdef ABL_STAT_NOATOM   // ablation (scripts/bench_fat.py): the whole reduction, no atomics (a never-taken store keeps it alive)
+            if (a1 == 12345.678f && a2 == 0.f) P.stat_sum[o] = 1.0;
+#else
             atomicAdd(P.stat_sum + o, (double)a1);
             atomicAdd(P.stat_sq + o, (double)a2);
+#endif
         }
     }
 }
