@@ -1233,7 +1233,9 @@ def test_reuse_g_forward_reproduces_the_two_forward_step(monkeypatch, dtype):
     a, b = run(False), run(True)
     print(f"{dtype}: two forwards d {a[0]:.6f} g {a[1]:.6f} | one forward d {b[0]:.6f} g {b[1]:.6f}; layout-in launches {a[3]} vs {b[3]}")
     assert b[3] < a[3], "the generator's input conversion should run once less"
-    tol = 1e-6 if dtype == F32 else 1e-5
+    # the two runs differ by the arrival order of D's float-atomic weight gradients (fp32 path: per-layer kernel), which the
+    # G-step's loss sees through D's update: measured 7e-7 ... 1.6e-6 run to run (fp32), bound at 3x
+    tol = 5e-6 if dtype == F32 else 2e-5
     assert abs(a[0] - b[0]) <= tol * abs(a[0]) and abs(a[1] - b[1]) <= tol * abs(a[1])
     flipped = total = 0
     for k in a[2]:
