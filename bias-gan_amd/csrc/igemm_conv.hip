@@ -1377,10 +1377,10 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
     // NO <= 128 on very many pixels (the entry flow): 128 x 256 tiles halve the tile count -- these launches are
     // HBM-bound and their statistics epilogue contends on 2 * NO atomic addresses once per tile
     static const long long flat_min = getenv("BGAMD_FLAT_MIN") ? atoll(getenv("BGAMD_FLAT_MIN")) : 2048;
-    // (HBM-bound launches only: with a long reduction -- the 3 x 3 128 -> 128 layers, 36 K-steps -- the 128 x 128 tile's
-    // three workgroups per CU are 4 % faster than two of 128 x 256; scripts/bench_variants.py)
-    const long long flat_ksteps = (long long)P.KH * P.KW * ((P.CK + 31) / 32);
-    const bool flat = !tall && dma_mode == 1 && tp_mode != 0 && (P.M + 127) / 128 >= flat_min && flat_ksteps <= 12 &&
+    // (also for the 3 x 3 128 -> 128 layers with their 36 K-steps: in the step's launch table the flat tile runs them in
+    // 566 / 525 us forward / data gradient at batch 8 against 706 / 620 with 128 x 128 tiles -- a micro-benchmark of the
+    // isolated launch had suggested the opposite by 4 %)
+    const bool flat = !tall && dma_mode == 1 && tp_mode != 0 && (P.M + 127) / 128 >= flat_min &&
                       (P.stat_group_pix == 0 || P.stat_group_pix % 256 == 0);
     const int tp = (wide || flat) ? 256 : TILE;
     P.tiles_c = (P.NO + tch - 1) / tch;

@@ -868,12 +868,13 @@ int plan_fat(GemmConvParams& P, bool big) {   // big: an operand beyond the clas
     const int bk = 64 / (int)sizeof(T);
     const long long kt = (long long)P.KH * P.KW * ((P.CK + bk - 1) / bk);
     if (mode != 2 && !big && ((P.NO <= 128 && !fat128) || kt < 8 || P.M < 16384)) return 0;
-    // Round 2 had measured the classic tiles level or up to 17 % ahead on hundreds of thousands of pixels with Cout <= 256
-    // (the decoder's 3x3 layers, the 256 -> 256 pointwise layers at 288x192) and kept them there; with this round's K loop
-    // (counted LDS waits, fragments read under the previous group) the fat tile is ahead there too: 256 -> 256 1x1 at
-    // 8 x 288 x 192 forward 137 -> 118 us, 3x3 493 -> 468 / 464 -> 442, 128 -> 256 forward 102 -> 91 (scripts/bench_variants.py).
-    static const bool classic_on_many = getenv("BGAMD_FAT_FEW_PIXELS_ONLY") != nullptr;
-    if (classic_on_many && mode != 2 && !big && P.M >= 131072 && (P.KH * P.KW > 1 || P.NO <= 256)) return 0;
+    // measured (scripts/bench_fat.py, and in the step's launch table): on hundreds of thousands of pixels with Cout <= 256
+    // (the decoder's 3x3 layers, the 256 -> 256 pointwise layers at 288x192) the classic tiles are level or ahead; on the
+    // ASPP's few-pixel layers the fat tile is 13-15 % ahead.  Re-measured in round 3 after the K-loop work
+    // (BGAMD_FAT_MANY_PIXELS=1): the fat tile gains 5-14 % on the 256-channel forward launches and loses 25 % on the
+    // 304 -> 256 data gradient (Cout' = 304: one and a fifth 256-row tiles) -- level in the step, rule kept.
+    static const bool fat_on_many = getenv("BGAMD_FAT_MANY_PIXELS") != nullptr;
+    if (!fat_on_many && mode != 2 && !big && P.M >= 131072 && (P.KH * P.KW > 1 || P.NO <= 256)) return 0;
     const int groups = P.stat_group_pix ? (int)(P.M / P.stat_group_pix) : 1;
     const long long gp = P.M / groups;
     if (gp * groups != P.M || gp >= (1LL << 31)) return 0;
