@@ -665,6 +665,7 @@ def test_conv_wgrad_grouped(case):
     (1, 16, 20, 1024, 256, 3, 12, 0, 2),     # 4 tiles x 9 taps > 32: taps as layers; dilation beyond half the map; 2 layers
     (3, 12, 20, 256, 512, 3, 2, 0, 1),       # W < 32: several rows per K-step; images change inside a K-step
     (1, 40, 48, 256, 256, 5, 1, 0, 1),       # 5 x 5: 25 taps
+    (1, 10, 12, 1024, 256, 3, 1, 0, 9),      # taps as layers, nine caller layers: two launches of at most 7 x 9 kernel layers
 ])
 def test_conv_wgrad_grouped_taps(case):
     """bg_conv2d_bwd_weight_grouped_taps: the weight gradient of k x k stride-1 'same' convolutions through the gang
