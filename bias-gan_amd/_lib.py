@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("BGAMD_LIB") or os.path.join(_HERE, "libbgamd.so")   #
 
 BF16, F32, FP8 = 0, 1, 2
 FP8_E4M3, FP8_E5M2 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -338,6 +338,21 @@ def call(name, *args):
 
 
 _SIDE_STREAMS = {}
+_OWNED_STREAMS = []     # raw handles from bg_stream_create, destroyed at interpreter exit
+
+
+def _destroy_side_streams():
+    while _OWNED_STREAMS:
+        h = _OWNED_STREAMS.pop()
+        try:
+            host_call("bg_stream_destroy", c_vp(h))
+        except Exception:   # noqa: BLE001 -- the runtime may already be tearing down
+            pass
+    _SIDE_STREAMS.clear()
+
+
+import atexit as _atexit
+_atexit.register(_destroy_side_streams)
 
 
 def side_stream(device, tag: str):
@@ -353,5 +368,6 @@ def side_stream(device, tag: str):
         out = c_vp()
         with torch.cuda.device(idx):
             host_call("bg_stream_create", C.byref(out))
+        _OWNED_STREAMS.append(out.value)
         s = _SIDE_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", idx))
     return s

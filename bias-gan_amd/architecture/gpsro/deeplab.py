@@ -385,6 +385,10 @@ class Xception(BGModule):
             low, x = ops.fork(x, 2)
         for i in range(2, 20):
             x = getattr(self, f"block{i}")(x, pre_activated=True, activate_output=True)
+        # data parallel: once backward has come back to here, the gradients of the exit flow and of everything registered
+        # after this Xception (ASPP, decoder / the critic's head: ~48 % of the generator's bytes) are final and their
+        # all-reduce starts under the middle and entry flow's backward (ops.GradMilestoneFn; no-op on one GPU)
+        x = ops.grad_milestone(x, self.arena(), list(self.block20.parameters()))
         x = self.block20(x, pre_activated=True, activate_output=False)
         x = conv_norm(self, self.conv3, self.bn3, x, act=True)
         x = conv_norm(self, self.conv4, self.bn4, x, act=True)

@@ -21,46 +21,84 @@ from .. import _lib as _L
 
 class FlatAllReduce:
     """SUM all-reduce of one flat tensor in `bucket_elems`-sized pieces on a side
-    stream.  Works on CPU tensors too (gloo), where it is simply asynchronous."""
+    stream.  Works on CPU tensors too (gloo), where it is simply asynchronous.
+
+    The buffer may be reduced in two instalments: launch_range(a, b) starts the reduction of a part that is already
+    final (the tail of the gradient arena when the backward pass has left the layers that live there:
+    ops.GradMilestoneFn), launch() the rest; finish() waits for both."""
 
     def __init__(self, flat: torch.Tensor, group=None, bucket_elems: int = 32 * 1024 * 1024):
         self.flat, self.group = flat, group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, int(bucket_elems))
         self.cuda = flat.is_cuda
-        self.stream = _L.side_stream(flat.device, f"allreduce-{id(self)}") if self.cuda else None
+        # one reduction stream per device (library-owned, never a PyTorch pool stream): every FlatAllReduce of a process
+        # shares it, so the number of streams does not grow with the number of networks / arena rebuilds
+        self.stream = _L.side_stream(flat.device, "allreduce") if self.cuda else None
         self.works = []
         self.launched = False
+        self.done = []          # element ranges already launched in this round (launch_range)
+        self.ms_pending = 0     # ops.GradMilestoneFn nodes created since the last finish() whose backward has not run
+        self.log = None         # tests: a list that receives ("launch", a, b) / ("finish",) in call order
 
-    def buckets(self):
-        n = self.flat.numel()
-        return [(o, min(o + self.bucket_elems, n)) for o in range(0, n, self.bucket_elems)]
+    def buckets(self, a=0, b=None):
+        n = self.flat.numel() if b is None else b
+        return [(o, min(o + self.bucket_elems, n)) for o in range(a, n, self.bucket_elems)]
+
+    def _issue(self, a, b, after=()):
+        if b <= a:
+            return
+        if self.log is not None:
+            self.log.append(("launch", a, b))
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            for s in after:
+                self.stream.wait_stream(s)
+            with torch.cuda.stream(self.stream):
+                for lo, hi in self.buckets(a, b):
+                    self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for lo, hi in self.buckets(a, b):
+                self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def launch_range(self, a, b, after=()):
+        """Start reducing flat[a:b] now: its values are final on the current stream (and on the streams in `after`)."""
+        if self.launched or self.world_size == 1:
+            return
+        a, b = max(0, int(a)), min(int(b), self.flat.numel())
+        for lo, hi in self.done:
+            if not (b <= lo or a >= hi):
+                raise RuntimeError("FlatAllReduce.launch_range: overlapping ranges in one round")
+        self._issue(a, b, after)
+        self.done.append((a, b))
 
     def launch(self):
-        """Start the reduction of the buffer's current contents (call after backward)."""
+        """Start the reduction of the buffer's current contents (call after backward): everything launch_range() has not
+        taken yet."""
         if self.launched or self.world_size == 1:
             self.launched = True
             return
-        if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
-            with torch.cuda.stream(self.stream):
-                for a, b in self.buckets():
-                    self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            for a, b in self.buckets():
-                self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        pos = 0
+        for lo, hi in sorted(self.done):
+            self._issue(pos, lo)
+            pos = max(pos, hi)
+        self._issue(pos, self.flat.numel())
         self.launched = True
 
     def finish(self):
         """Make the reduced values visible to the current stream (launches first if nobody did)."""
         if not self.launched:
             self.launch()
+        if self.log is not None:
+            self.log.append(("finish",))
         for w in self.works:
             w.wait()
         self.works = []
         if self.cuda and self.world_size > 1:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
         self.launched = False
+        self.done = []
+        self.ms_pending = 0
 
 
 class DistributedModel(nn.Module):

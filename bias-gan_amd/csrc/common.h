@@ -77,6 +77,14 @@ struct Chunk {
     }
 };
 
+// num_records of a buffer descriptor whose base has been moved forward inside a tensor: the bytes left behind the base,
+// clamped to [0, 2^31 - 1].  The LOWER clamp matters: a base at or beyond the tensor's end gives a negative remainder,
+// which the hardware reads as ~4 G records -- every offset, the out-of-range marker 0x80000000 included, would then be
+// in range (the fault fixed in 9d5668e; tests: test_descriptor_ranges_past_the_tensor_end).
+__device__ __host__ inline int bg_records(long long rem) {
+    return (int)(rem < 0 ? 0 : rem < 0x7fffffffLL ? rem : 0x7fffffffLL);
+}
+
 __device__ inline float lrelu_f(float z) { return z >= 0.f ? z : LRELU_SLOPE * z; }
 // activation codes of the norm_act entry points: 0 none, 1 LeakyReLU(0.2), 2 ReLU (PCBActiv3d, infill3d.py:103-106)
 __device__ inline float act_slope(int act) { return act == 2 ? 0.f : LRELU_SLOPE; }

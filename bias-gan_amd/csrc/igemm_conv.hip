@@ -1035,12 +1035,12 @@ __global__ __launch_bounds__(512) void wgrad_gang_kernel(WgGangParams P) {
         const long long rem_a = (((long long)P.M - p0 - 1) * P.ldy + P.Co) * 2,
                         rem_b = (((long long)P.M - p0 - shift - 1) * P.ldx + P.Ci) * 2;
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(dyp + p0 * P.ldy), 0, (int)(rem_a < 0x7fffffffLL ? rem_a : 0x7fffffffLL), 0x00020000);
+            const_cast<bf16_t*>(dyp + p0 * P.ldy), 0, bg_records(rem_a), 0x00020000);
         // (with a negative shift the base lies in front of the tensor for the first rows: those lanes are masked below)
         // (a segment near the end with a positive shift starts beyond the tensor: no records at all -- a negative count
         // would read as 4 G records and let the out-of-range marker through)
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(xp + (p0 + shift) * P.ldx), 0, (int)(rem_b < 0 ? 0 : rem_b < 0x7fffffffLL ? rem_b : 0x7fffffffLL), 0x00020000);
+            const_cast<bf16_t*>(xp + (p0 + shift) * P.ldx), 0, bg_records(rem_b), 0x00020000);
         int va[2], vb[2];
         int xn[2], xh[2], xw[2];        // TAPS: image, row, column of the dy pixel each x piece row belongs to
 #pragma unroll

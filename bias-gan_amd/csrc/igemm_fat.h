@@ -187,7 +187,7 @@ __device__ __forceinline__ void conv_epilogue_fat(const GemmConvParams& P, f32x4
     T* out_tile = reinterpret_cast<T*>(P.out) + (long long)p_base * P.ldo;
     const long long rem = (((long long)P.M - p_base - 1) * P.ldo + P.NO) * ES;
     const __amdgpu_buffer_rsrc_t rs_out =
-        __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, bg_records(rem), 0x00020000);
     const bool stats = P.stat_sum != nullptr;
     char* region = smem + wave * REGION;                               // this wave's transposition buffer
     float* red = reinterpret_cast<float*>(smem + WM * WN * REGION);   // [wave_p][TM channels][2]
@@ -316,7 +316,7 @@ __device__ __forceinline__ void conv_epilogue_fat_impl(const GemmConvParams& P, 
     T* out_tile = reinterpret_cast<T*>(P.out) + (long long)p_base * P.ldo;
     const long long rem = (((long long)P.M - p_base - 1) * P.ldo + P.NO) * ES;
     const __amdgpu_buffer_rsrc_t rs_out =
-        __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, (int)(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(out_tile, 0, bg_records(rem), 0x00020000);
     constexpr bool stats = STATS;   // compile-time: with run-time flags the per-value code carried 216 selects and 435 moves
     char* region = smem + wave * REGION;                               // this wave's transposition buffer
     float* red = reinterpret_cast<float*>(smem + WM * WN * REGION);   // [wave_p][TM channels][2]
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
     const long long base_pix = ((long long)n0 * P.IH + row0c) * P.IW;
     const long long in_rem = (((long long)P.N * P.IH * P.IW - base_pix - 1) * P.ldi + P.CK) * ES;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(reinterpret_cast<const T*>(P.in) + base_pix * P.ldi), 0, (int)(in_rem < 0x7fffffffLL ? in_rem : 0x7fffffffLL), 0x00020000);
+        const_cast<T*>(reinterpret_cast<const T*>(P.in) + base_pix * P.ldi), 0, bg_records(in_rem), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.w), 0, P.w_bytes, 0x00020000);
 
     const int lr = lane / CPR, lc = lane % CPR;

@@ -16,7 +16,7 @@ from ..architecture.gpsro import deeplab_gan as dxg
 from ..comm.distributed import DistributedModel
 from .. import ops
 from .._lib import side_stream as _side_stream
-from ..graphs import NoGradGraph
+from ..graphs import HostStepState, NoGradGraph, roll_fp8_sites
 from ..runtime import StatsPool
 
 
@@ -278,14 +278,17 @@ class GANTrainer:
         if "graph" not in e:
             # A capture can fail where the eager step works (a host sync inside a user-supplied loss or gradient-penalty
             # function): the optimisers' step counts are rolled back, the configuration is marked and runs eagerly for good.
-            t_before = [o._t for o in opts]
+            # The attempted capture runs _eager_step on the host: whatever that advanced before it died (optimiser step counts,
+            # LR schedules -- _finish_d() steps D's -- BatchNorm forward counts, statistics-pool cursor, fp8 site sets, the
+            # step counter) is put back, so that the eager re-run below is this iteration's ONLY step (graphs.HostStepState).
+            snap = HostStepState(self, (self.generator, self.discriminator), (self.d_opt, self.g_opt),
+                                 (self.d_scheduler, self.g_scheduler))
             for o in opts:
                 o.prepare_replay()
             try:
                 self._capture(e, key, opts, pool)
             except Exception as err:   # noqa: BLE001 -- whatever the capture raised, the eager path is the fallback
-                for o, t in zip(opts, t_before):
-                    o._t = t
+                snap.restore()
                 self._graph_failed.add(key)
                 self._graphs.pop(key, None)
                 self._d_pending, self._g_ahead, self._want_g_ahead = False, None, False
@@ -354,10 +357,7 @@ class GANTrainer:
         if train_generator:
             g_loss = self.g_step(inputs, outputs_real, masks)
         self._finish_d()
-        for net in (self.generator, self.discriminator):   # fp8 operand path: next step's exponents from this step's maxima
-            a = getattr(_unwrap(net), "_bg_arena", None)
-            if a is not None and a.fp8:
-                a.roll_fp8()
+        roll_fp8_sites(self.generator, self.discriminator)   # fp8 operand path: next step's exponents from this step's maxima
         self.step_count += 1
         return d_loss, g_loss
 
@@ -382,6 +382,8 @@ class GANTrainer:
         scheds = [self.g_scheduler, self.d_scheduler]
         snap_sched = [None if sc is None else copy.deepcopy(sc.state_dict()) for sc in scheds]
         rng, step = torch.get_rng_state(), self.step_count
+        dev = next(nets[0].parameters()).device
+        rng_dev = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None   # noise_on_device generators draw from it
         try:
             self._eager_step(inputs, outputs_real, masks)
         finally:
@@ -396,6 +398,8 @@ class GANTrainer:
                 if sc is not None:
                     sc.load_state_dict(sd)
             torch.set_rng_state(rng)
+            if rng_dev is not None:
+                torch.cuda.set_rng_state(rng_dev, dev)
             self.step_count = step
             self._d_pending, self._g_ahead = False, None
 
@@ -440,17 +444,31 @@ class GANTrainer:
     def save_checkpoint(self, path, epoch=0):
         """{step, epoch, generator, discriminator, g_opt, d_opt, amp}: the reference's dictionary, with
         the reference's state_dict key names (DistributedModel adds the 'module.' prefix like DDP)."""
-        torch.save({"step": self.step_count, "epoch": epoch,
-                    "generator": {k: v.detach().clone().contiguous() for k, v in self.generator.state_dict().items()},
-                    "discriminator": {k: v.detach().clone().contiguous()
-                                      for k, v in self.discriminator.state_dict().items()},
-                    "g_opt": self.g_opt.state_dict(), "d_opt": self.d_opt.state_dict(), "amp": None}, path)
+        ck = {"step": self.step_count, "epoch": epoch,
+              "generator": {k: v.detach().clone().contiguous() for k, v in self.generator.state_dict().items()},
+              "discriminator": {k: v.detach().clone().contiguous()
+                                for k, v in self.discriminator.state_dict().items()},
+              "g_opt": self.g_opt.state_dict(), "d_opt": self.d_opt.state_dict(), "amp": None}
+        # fp8 operand path only (an extra key the reference's loader never reads): the quantisation sites' exponents and
+        # which of them are calibrated, so that a resumed run does not repeat a bf16 calibration step
+        fp8 = {name: st for name, st in (("generator", getattr(_unwrap(self.generator), "_bg_arena", None)),
+                                          ("discriminator", getattr(_unwrap(self.discriminator), "_bg_arena", None)))
+               if st is not None and st.fp8_state() is not None}
+        if fp8:
+            ck["bgamd_fp8"] = {name: a.fp8_state() for name, a in fp8.items()}
+        torch.save(ck, path)
 
     def load_checkpoint(self, path, comm, device):
         # the optimiser moments are flat buffers over the parameter arenas: build those first
         _unwrap(self.generator).arena(), _unwrap(self.discriminator).arena()
         self.step_count, epoch = comm.init_gan_training_state(_unwrap(self.generator), _unwrap(self.discriminator),
                                                               self.g_opt, self.d_opt, path, device)
+        import os
+        if path is not None and os.path.isfile(path):
+            st = torch.load(path, map_location="cpu").get("bgamd_fp8")
+            if st:
+                _unwrap(self.generator).arena().load_fp8_state(st.get("generator"))
+                _unwrap(self.discriminator).arena().load_fp8_state(st.get("discriminator"))
         return self.step_count, epoch
 
 

@@ -7,6 +7,7 @@ in train mode, so BatchNorm statistics move) while the updates follow a schedule
 from __future__ import annotations
 
 from ..architecture.gpsro import deeplab3d_gan as dxg3
+from ..graphs import roll_fp8_sites
 from ..runtime import StatsPool
 from .train_gan import GANTrainer
 
@@ -51,6 +52,7 @@ class GANTrainer3d(GANTrainer):
         d_loss = self.d_step(inputs, outputs_real, labels, eta)
         g_loss = self.g_step(inputs, outputs_real, masks)
         self._finish_d()
+        roll_fp8_sites(self.generator, self.discriminator)
         self.step_count += 1
         return d_loss, g_loss
 

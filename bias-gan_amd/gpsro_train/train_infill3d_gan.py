@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 
 from ..comm.distributed import DistributedModel
-from ..graphs import NoGradGraph
+from ..graphs import HostStepState, NoGradGraph, roll_fp8_sites
 from ..runtime import StatsPool
 
 
@@ -119,14 +119,15 @@ class InfillGANTrainer:
         opts = ([self.d_opt] if train_d else []) + ([self.g_opt] if train_g else [])
         pool = StatsPool.get(dev)
         if "graph" not in e:
-            t_before = [o._t for o in opts]
+            snap = HostStepState(self, (self.generator, self.discriminator), (self.d_opt, self.g_opt),
+                                 (self.d_scheduler, self.g_scheduler),
+                                 extra_attrs=("last_flags", "last_terms", "_d_acc", "_acc_pending"))
             for o in opts:
                 o.prepare_replay()
             try:
                 self._capture(e, key, opts, pool)
             except Exception as err:   # noqa: BLE001 -- whatever the capture raised, the eager path is the fallback
-                for o, t in zip(opts, t_before):
-                    o._t = t
+                snap.restore()         # step counts, LR schedules, BatchNorm counters, pool cursor: graphs.HostStepState
                 self._graph_failed.add(key)
                 self._graphs.pop(key, None)
                 import warnings
@@ -242,6 +243,7 @@ class InfillGANTrainer:
             for p in self._d_params:
                 p.requires_grad_(True)
         self.last_terms = {k: v.detach() for k, v in terms.items()}
+        roll_fp8_sites(self.generator, self.discriminator)
         self.step_count += 1
         return d_loss.detach(), g_loss.detach()
 

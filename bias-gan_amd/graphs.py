@@ -93,3 +93,58 @@ class NoGradGraph:
              "nbt": [(m, k) for m, k in nbt if k]}
         g.replay()                                      # capture records, it does not execute
         return e
+
+
+def roll_fp8_sites(*nets):
+    """End of a training iteration on the fp8 operand path: next step's exponents from this step's recorded maxima, for
+    every network that is in fp8 mode (no-op otherwise).  Every trainer's _eager_step ends with it -- without the roll no
+    quantisation site ever becomes ready and the GEMMs stay on bf16 operands while paying for the amax passes."""
+    for net in nets:
+        a = getattr(_unwrap(net), "_bg_arena", None)
+        if a is not None and a.fp8:
+            a.roll_fp8()
+
+
+class HostStepState:
+    """Everything a training step advances on the HOST, so that a step that died half-way (a failed whole-step capture:
+    GANTrainer._graph_step) can be taken back before the eager re-run -- otherwise the LR schedule runs one step ahead
+    for the rest of the run, num_batches_tracked over-counts and fp8 sites become 'ready' on data they never saw.
+
+    Snapshot: the optimisers' step counts and learning rates, the schedulers' state, every BatchNorm's pending forward
+    count, the trainer's step counter and pending flags, the statistics pool's slot cursor and the fp8 site sets of the
+    parameter arenas.  Device memory is not part of it: a capture records launches, it does not run them."""
+
+    def __init__(self, trainer, nets, opts, scheds, extra_attrs=()):
+        import copy
+        self.trainer, self.opts, self.scheds = trainer, list(opts), [s for s in scheds if s is not None]
+        self.t = [o._t for o in self.opts]
+        self.lrs = [[g["lr"] for g in o.param_groups] for o in self.opts]
+        self.sched_sd = [copy.deepcopy(s.state_dict()) for s in self.scheds]
+        self.mods = [m for n in nets for m in _unwrap(n).modules() if "_bg_nbt_pending" in m.__dict__]
+        self.nbt = [m.__dict__["_bg_nbt_pending"] for m in self.mods]
+        self.nets = [_unwrap(n) for n in nets]
+        self.arenas = [a for a in (getattr(n, "_bg_arena", None) for n in self.nets) if a is not None and getattr(a, "fp8", False)]
+        self.sites = [(set(a._site_seen), set(a._site_ready), a.sites_ready) for a in self.arenas]
+        self.pools = [(p, p.used) for p in StatsPool.all()]
+        self.attrs = {k: getattr(trainer, k) for k in ("step_count",) + tuple(extra_attrs) if hasattr(trainer, k)}
+
+    def restore(self):
+        for o, t, lrs in zip(self.opts, self.t, self.lrs):
+            o._t = t
+            for g, lr in zip(o.param_groups, lrs):
+                g["lr"] = lr
+        for s, sd in zip(self.scheds, self.sched_sd):
+            s.load_state_dict(sd)
+        seen = set(map(id, self.mods))
+        for m, k in zip(self.mods, self.nbt):
+            m.__dict__["_bg_nbt_pending"] = k
+        for n in self.nets:                      # counters that did not exist at snapshot time
+            for m in n.modules():
+                if id(m) not in seen and m.__dict__.get("_bg_nbt_pending", 0):
+                    m.__dict__["_bg_nbt_pending"] = 0
+        for a, (seen_, ready, flag) in zip(self.arenas, self.sites):
+            a._site_seen, a._site_ready, a.sites_ready = set(seen_), set(ready), flag
+        for p, used in self.pools:
+            p.used = used
+        for k, v in self.attrs.items():
+            setattr(self.trainer, k, v)

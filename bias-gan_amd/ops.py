@@ -257,6 +257,78 @@ def wgrad_group_flush(key, only_sig=None):
             L.call("bg_conv2d_bwd_weight_grouped", L.BF16, tbl.data_ptr(), len(jobs), rows, cin, cout, ldx, ldy)
 
 
+# ------------------------------------------------------------------ data parallel: early reduction of the arena's tail
+# Parameters sit in the gradient arena in module order; backward visits them in reverse.  When the backward pass crosses
+# a milestone placed in front of module M in forward order, every gradient of M and of everything registered after it is
+# final (queued on this stream or on the weight-gradient stream) -- provided the arena's tail is exactly those modules.
+# The milestone's backward then flushes the grouped weight gradients collected so far and starts the all-reduce of the
+# tail on the reduction stream (comm.distributed.FlatAllReduce.launch_range) while the rest of the pass runs: the
+# reference's apex DDP overlaps its buckets with backward the same way (comm/distributed.py:195-199).
+_DDP_EARLY = _os.environ.get("BGAMD_DDP_EARLY", "1") != "0"
+
+
+def arena_tail_offset(arena: Arena, first_tail_params) -> Optional[int]:
+    """Arena offset from which on every slot belongs to a module registered at or after `first_tail_params`' owner, or
+    None when the layout does not have that shape (then nothing is reduced early)."""
+    ids = {id(p) for p in first_tail_params}
+    offs = [s.off for s in arena.slots if id(s.param) in ids]
+    if not offs:
+        return None
+    off0 = min(offs)
+    seen_tail = False
+    for s in arena.slots:                       # slots are in registration order with increasing offsets
+        if s.off >= off0:
+            seen_tail = True
+        elif seen_tail:
+            return None
+    return off0
+
+
+class GradMilestoneFn(torch.autograd.Function):
+    """Identity.  backward: the gradient arena from `off` on is final -> start its all-reduce (data parallel only)."""
+
+    @staticmethod
+    def forward(ctx, x, probe, arena: Arena, off: int):
+        # `probe` is one of the tail's parameters: with frozen weights (the G-step's critic; the gradient penalty, which
+        # freezes the critic around its autograd.grad) grad_milestone() inserts no node, and needs_input_grad[1] is False
+        # for a node created while the probe did not require a gradient
+        ctx.arena, ctx.off = arena, off
+        # a network may be called more than once before one backward pass (D(real) and D(fake)): the tail is final when the
+        # LAST of these nodes has run, so they are counted (reset by FlatAllReduce.finish())
+        arena.ddp.ms_pending += 1
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ddp = getattr(ctx.arena, "ddp", None)
+        if ddp is not None:
+            ddp.ms_pending -= 1
+        if (ctx.needs_input_grad[1] and ddp is not None and ddp.world_size > 1 and ddp.ms_pending == 0
+                and not (g.is_cuda and torch.cuda.is_current_stream_capturing())):
+            after = ()
+            if g.is_cuda:
+                key = g.device.index if g.device.index is not None else torch.cuda.current_device()
+                wgrad_group_flush(key)                        # grouped weight gradients of the tail: launch them now
+                ent = _WG_STREAMS.get(key)
+                after = (ent[0],) if ent is not None else ()
+            ddp.launch_range(ctx.off, ctx.arena.numel, after)
+        return g, None, None, None
+
+
+def grad_milestone(x, arena: Arena, first_tail_params):
+    """Mark the point in the forward pass behind which (in module order) the arena's tail lives; see GradMilestoneFn."""
+    ddp = getattr(arena, "ddp", None)
+    if (not _DDP_EARLY or ddp is None or ddp.world_size == 1 or not x.requires_grad
+            or not first_tail_params or not first_tail_params[0].requires_grad):   # frozen weights (the G-step's critic): nothing to reduce
+        return x
+    cache = arena.__dict__.setdefault("_tail_offs", {})
+    key = id(first_tail_params[0])
+    if key not in cache:
+        cache[key] = arena_tail_offset(arena, first_tail_params)
+    off = cache[key]
+    return x if off is None else GradMilestoneFn.apply(x, first_tail_params[0], arena, off)
+
+
 # ------------------------------------------------------------------ layout boundary
 class ToInternal(torch.autograd.Function):
     """NCHW fp32 (module boundary, as the reference passes tensors) -> NHWC compute dtype."""
@@ -405,6 +477,18 @@ def fp8_amax_only(t: torch.Tensor, fmt: int, exp_ptr: int, amax_ptr: int):
     fp8_quant(t, fmt, exp_ptr, amax_ptr)
 
 
+def fp8_copy_of(t: torch.Tensor):
+    """The producer-written fp8 copy attached to `t` (t._bg_fp8), or None -- also None when `t` has been written since the
+    copy was made (the autograd engine accumulating a second gradient into the same tensor in place, a tensor hook): the
+    attribute survives such a write, the copy would be stale, so the consumer quantises again."""
+    q = getattr(t, "_bg_fp8", None)
+    if q is None:
+        return None
+    if len(q) >= 4 and (q[2] != t._version or q[3] != t.data_ptr()):
+        return None
+    return q
+
+
 def fp8_tag_output(y: torch.Tensor, arena: Arena, wslot: ParamSlot, kh, kw):
     """Mark a dense convolution's output with the quantisation site of its OUTPUT GRADIENT: the BatchNorm backward that
     later produces that gradient writes the e5m2 copy itself (bg_norm_act_bwd_apply_stats_q8) instead of leaving a
@@ -425,7 +509,7 @@ def _apply_stats_maybe_q8(q_site, dx, args, n, h, w, c):
             dxq = torch.empty((n, h, w, ldq), dtype=torch.uint8, device=dx.device)
             L.call("bg_norm_act_bwd_apply_stats_q8", *args, dxq.data_ptr(), ldq, ep, ap)
             qa.site_seen(qw, grad=True)
-            dx._bg_fp8 = (dxq[..., :cq], ep)
+            dx._bg_fp8 = (dxq[..., :cq], ep, dx._version, dx.data_ptr())   # fp8_copy_of() checks that dx is still these bytes
             return
         # not calibrated yet: the plain kernel, then one pass that only records the site's max |dx| (the consuming
         # convolution would not take it for layers below the stand-alone threshold)
@@ -453,7 +537,7 @@ class Conv2dFn(torch.autograd.Function):
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
         splits = splitk_plan(n * ho * wo, kp, cin, kh, kw, x.dtype) if bslot is None else 0
-        xq = getattr(x, "_bg_fp8", None)
+        xq = fp8_copy_of(x)
         use8 = x.dtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw, prequantised=xq is not None)
         if use8:
             # fp8 operands: the input's e4m3 copy (the producer's, if it made one; else one quantisation pass) against the
@@ -508,7 +592,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = new_act(n, h, w, cin, xdtype, xdev)
             d2 = L.ConvDesc(L.dt(xdtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(dx), ld_of(g))
             splits = splitk_plan(n * h * w, cin, kp, kh, kw, xdtype)
-            gq = getattr(g, "_bg_fp8", None)
+            gq = fp8_copy_of(g)
             use8 = (xdtype == torch.bfloat16 and not splits and cin >= 64
                     and fp8_layer_ok(arena, wslot, kh, kw, grad=True, prequantised=gq is not None))
             if use8:

@@ -90,6 +90,10 @@ class StatsPool:
         for p in cls._pools.values():
             p.reset()
 
+    @classmethod
+    def all(cls):
+        return list(cls._pools.values())
+
 
 _ARENA_OF = {}  # id(param) -> weakref to its arena
 
@@ -216,6 +220,26 @@ class Arena:
             self._site_ready |= self._site_seen
             self._site_seen.clear()
             self.sites_ready = True
+
+    def fp8_state(self):
+        """The delayed-scaling state a checkpoint must carry for a resumed fp8 run to continue like an uninterrupted one:
+        every site's exponent and which sites are calibrated (None outside fp8 mode)."""
+        if not (self.fp8 and self.n_fp8_layers):
+            return None
+        return {"site_exp": self.site_exp.detach().cpu().clone(), "site_ready": sorted(self._site_ready),
+                "names": [s.name for s in self.slots if s.krsc is not None]}
+
+    def load_fp8_state(self, st):
+        """Inverse of fp8_state(); a state from a different network layout is ignored (the run recalibrates)."""
+        if st is None or not (self.fp8 and self.n_fp8_layers):
+            return False
+        if list(st.get("names", [])) != [s.name for s in self.slots if s.krsc is not None]:
+            return False
+        self.site_exp.copy_(st["site_exp"].to(self.site_exp.device))
+        self._site_ready = set(int(i) for i in st["site_ready"])
+        self._site_seen = set()
+        self.sites_ready = bool(self._site_ready)
+        return True
 
     def site_ready(self, s: ParamSlot, grad: bool) -> bool:
         """Has this site's exponent been derived from data it saw?"""

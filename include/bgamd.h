@@ -55,7 +55,7 @@ extern "C" {
 #define BG_E_ARG (-1)    /* bad argument / shape the kernels do not support */
 #define BG_E_LAUNCH (-2) /* hipLaunch failed (message carries hipGetErrorString) */
 
-#define BG_ABI_VERSION 1
+#define BG_ABI_VERSION 2
 
 int bg_abi_version(void);
 const char* bg_last_error(void);

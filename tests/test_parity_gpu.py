@@ -817,10 +817,13 @@ def _ddp_oracle_worker(rank, world, port, q):
     torch.manual_seed(100 + rank)
     labels = crit.draw_labels()
     x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 3000 + rank))
+    tr.generator._prepare(), tr.discriminator._prepare()       # the reducers exist now: record what they launch
+    G.arena().ddp.log, D.arena().ddp.log = [], []
     tr.step(x, y, labels=labels)
     torch.cuda.synchronize()
     out = {"D": {k: (cs(v)[1], _signed_projection(i, v)) for i, (k, v) in enumerate(D.named_parameters())},
-           "G": {k: (cs(v)[1], _signed_projection(i, v)) for i, (k, v) in enumerate(G.named_parameters())}}
+           "G": {k: (cs(v)[1], _signed_projection(i, v)) for i, (k, v) in enumerate(G.named_parameters())},
+           "trace": {"G": (list(G.arena().ddp.log), G.arena().numel), "D": (list(D.arena().ddp.log), D.arena().numel)}}
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -848,6 +851,14 @@ def test_data_parallel_update_is_the_oracle_average():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res[0] == res[1]
+    # the tail of each gradient arena (exit flow, ASPP + decoder / the critic's head) went out EARLY, from inside the
+    # backward pass (ops.GradMilestoneFn), the rest when the pass ended; one finish each
+    for net in ("G", "D"):
+        log, numel = res[0]["trace"][net]
+        launches = [e for e in log if e[0] == "launch"]
+        assert len(launches) == 2 and 0 < launches[0][1] < numel and launches[0][2] == numel, (net, log)
+        assert launches[1][1:] == (0, launches[0][1]) and [e[0] for e in log].count("finish") == 1, (net, log)
+        assert launches[0][1] < 0.75 * numel, (net, launches[0][1], numel)      # a real share of the bytes, not a sliver
     # ---- the oracle: two replicas of the D-step, then of the G-step, gradients averaged
     gspec, dspec = orc.generator_spec(c, c, 0, "batch"), orc.discriminator_spec(c, h, w, "batch")
     gk, dk = orc.trainable_keys(gspec), orc.trainable_keys(dspec)
@@ -1046,6 +1057,70 @@ def test_whole_step_graph_matches_eager(monkeypatch, mode, lr):
         assert rel_err(g["rm"], e["rm"]) <= 1e-5
     else:       # six +-lr-like moves of every weight: the abs-sums of both schedules grow alike
         assert abs(e["gw"][1] - g["gw"][1]) <= 2e-3 * e["gw"][1] and abs(e["dw"][1] - g["dw"][1]) <= 2e-3 * e["dw"][1]
+
+
+class _SyncingL1(torch.nn.Module):
+    """A user-supplied regression criterion that reads a value back on the host: works eagerly, cannot be captured."""
+
+    def __init__(self):
+        super().__init__()
+        self.inner = losses.L1Loss()
+        self.seen = []
+
+    def forward(self, pred, target):
+        loss = self.inner(pred, target)
+        self.seen.append(loss.item())          # .item() = a host synchronisation: illegal during stream capture
+        return loss
+
+
+def test_failed_step_capture_falls_back_without_advancing_the_host_state(monkeypatch):
+    """the attempted whole-step capture runs the step on the host first; when it dies in the G-step
+    (here: a criterion that calls .item()), D's LR schedule, the BatchNorm forward counts, the step counter and the
+    statistics-pool cursor have already advanced.  The fall-back must put them back before the eager re-run
+    (graphs.HostStepState): LR, num_batches_tracked, Adam step counts and -- with the learning rate at 0 -- every step's
+    losses must equal a run that was eager from the start; the configuration then stays eager."""
+    import warnings
+    c, h, w, n = 4, 64, 64, 2
+    sched = {"type": "multistep", "milestones": "1 3", "decay_rate": "0.5"}
+
+    def run(flag, lr):
+        monkeypatch.setenv("BGAMD_STEP_GRAPH", flag)
+        G, _ = build_generator(c, 41, F32)
+        D, _ = build_discriminator(c, h, w, 42, F32)
+        G.train(), D.train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        g_opt = ph.get_optimizer(G.parameters(), "Adam", lr, 1e-8, 0.0)
+        d_opt = ph.get_optimizer(D.parameters(), "Adam", lr, 1e-8, 0.0)
+        tr = GANTrainer(G, D, g_opt, d_opt, crit, _SyncingL1(), g_scheduler=ph.get_lr_schedule(lr, sched, g_opt),
+                        d_scheduler=ph.get_lr_schedule(lr, sched, d_opt))
+        out, lrs = [], []
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            for s_ in range(5):
+                torch.manual_seed(300 + s_)
+                x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 700 + s_))
+                d_loss, g_loss = tr.step(x, y)
+                out.append((float(d_loss), float(g_loss)))
+                lrs.append((g_opt.param_groups[0]["lr"], d_opt.param_groups[0]["lr"]))
+        torch.cuda.synchronize()
+        sd, sdd = G.state_dict(), D.state_dict()
+        return dict(losses=out, lrs=lrs, t=(g_opt._t, d_opt._t), step=tr.step_count,
+                    nbt=(int(sd["model.xception_features.bn1.num_batches_tracked"]), int(sdd["xception_features.bn1.num_batches_tracked"])),
+                    failed=len(getattr(tr, "_graph_failed", ())), graphs=len(getattr(tr, "_graphs", {})),
+                    warned=sum("capture failed" in str(w_.message) for w_ in wlist), calls=len(tr.criterion_regression.seen),
+                    rm=sd["model.xception_features.bn1.running_mean"].cpu())
+
+    for lr in (0.0, 1e-3):
+        e, g = run("0", lr), run("1", lr)
+        assert e["failed"] == 0 and g["failed"] == 1 and g["graphs"] == 0 and g["warned"] == 1
+        for k in ("lrs", "t", "step", "nbt"):
+            assert e[k] == g[k], (lr, k, e[k], g[k])
+        assert e["step"] == 5 and e["t"] == (5, 5) and e["nbt"] == (10, 15)
+        assert g["calls"] == e["calls"] + 1            # the aborted capture reached the criterion once more; nothing else ran twice
+        if lr == 0.0:
+            for i, (a, b) in enumerate(zip(e["losses"], g["losses"])):
+                assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]), (i, a, b)
+            assert rel_err(g["rm"], e["rm"]) <= 1e-5
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
