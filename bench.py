@@ -225,6 +225,22 @@ def host_floor(c, n, dtype, device, mode):
             os.environ["BGAMD_STEP_GRAPH"] = old_env
 
 
+def _half(fam, pick, mfma_peak_tflops):
+    """Sum of the per-entry-point records `pick` selects: launches, single-stream kernel time, algorithmic FLOP / bytes and
+    the fraction of the bound that applies (MFMA peak for the GEMM half, 8 TB/s for the element-wise half)."""
+    sel = [v for k, v in fam.items() if pick(k)]
+    n, secs = sum(v[0] for v in sel), sum(v[1] for v in sel)
+    flops, nbytes = sum(v[2] for v in sel), sum(v[3] for v in sel)
+    out = {"launches": n, "total_ms": 1e3 * secs}
+    if mfma_peak_tflops is not None:
+        tf = flops / secs * 1e-12 if secs > 0 else 0.0
+        out.update(alg_tflop=flops * 1e-12, tflops=tf, frac=tf / mfma_peak_tflops, peak=mfma_peak_tflops, unit="TFLOP/s")
+    else:
+        tb = nbytes / secs * 1e-12 if secs > 0 else 0.0
+        out.update(alg_gb=nbytes * 1e-9, tbps=tb, frac=tb / 8.0, peak=8.0, unit="TB/s")
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -447,6 +463,11 @@ def main():
             # weight gradients and the layers below the fp8 threshold compute in bf16)
             "step_conv_stack_frac": None if walg is None else value / world * walg / PEAK_BF16_TFLOPS,
             # per entry point: MFMA-bound ones in TFLOP/s, HBM-bound ones in algorithmic GB/s (peak 8000)
+            # the two halves of the step, so that the driver-run line tells the whole story: every GEMM
+            # entry point together (MFMA-bound and HBM-bound launches: all of the step's conv FLOPs over all of their time)
+            # against the MFMA peak, and every other kernel together against the HBM peak
+            "all_gemm": _half(fam, lambda k: k.startswith("bg_conv2d"), peak_of("")),
+            "elementwise": _half(fam, lambda k: not k.startswith("bg_conv2d"), None),
             "families": {k: {"launches": v[0], "total_ms": 1e3 * v[1], "tflops": (v[2] / v[1] * 1e-12 if v[1] > 0 else 0.0),
                              "alg_gbps": (v[3] / v[1] * 1e-9 if v[1] > 0 else 0.0)}
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},

@@ -69,6 +69,8 @@ _SIGS = {
     "bg_dwconv3x3_bwd_data": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_fused": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp,
                                c_vp, c_vp],
+    "bg_dwconv3x3_bwd_fork": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32,
+                              c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_weight": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_dwconv3x3_bwd_data_add": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
     "bg_dwconv3x3_fwd_pre": [C.POINTER(DwDesc), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
@@ -249,6 +251,9 @@ def _alg_bytes(name, a) -> float:
     if name == "bg_dwconv3x3_bwd_fused":      # dy in, x in, da out
         d = a[0]
         return float(d.N) * 3 * d.H * d.W * d.C * _es(d.dtype)
+    if name == "bg_dwconv3x3_bwd_fork":       # dy in, a0 in, skip in, z in, gout out
+        d = a[0]
+        return float(d.N) * 5 * d.H * d.W * d.C * _es(d.dtype)
     if name == "bg_dwconv3x3_bwd_data_add":   # dy in, addend in, dx out
         d = a[0]
         return float(d.N) * 3 * d.H * d.W * d.C * _es(d.dtype)

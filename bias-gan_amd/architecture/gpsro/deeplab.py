@@ -161,7 +161,7 @@ def norm_act_dw(owner: BGModule, m: nn.BatchNorm2d, x, stats, dw: "Conv2d"):
                                      stats, groups, dw.dilation[0])
 
 
-def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False, skip_dw=False, defer_norm=False):
+def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False, skip_dw=False, defer_norm=False, offer_tail=False):
     """conv (Conv2d or SeparableConv2d_same) -> norm (+ residual) (+ LeakyReLU).  When the
     normaliser is a training-mode BatchNorm2d its batch statistics come out of the
     convolution's epilogue instead of a separate pass over the conv output.
@@ -188,11 +188,13 @@ def conv_norm(owner: BGModule, conv, m: nn.Module, x, res=None, act=False, skip_
         y = conv(x, stats) if stats is not None else conv(x)
     if defer_norm:
         return y, stats
-    return apply_norm(owner, m, y, res=res, act=act, stats=stats)
+    return apply_norm(owner, m, y, res=res, act=act, stats=stats, offer_tail=offer_tail)
 
 
-def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False, stats=None):
-    """norm (+ residual) (+ LeakyReLU(0.2)) in one pass over the activation."""
+def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False, stats=None, offer_tail=False):
+    """norm (+ residual) (+ LeakyReLU(0.2)) in one pass over the activation.  offer_tail: the caller guarantees that the
+    result has exactly ONE consumer (the next Block): a training-mode BatchNorm then offers that consumer the first half of
+    its backward (ops.NormTail)."""
     kind = _norm_kind(m)
     if kind == "identity":
         if res is None and not act:
@@ -212,7 +214,7 @@ def apply_norm(owner: BGModule, m: nn.Module, x, res=None, act=False, stats=None
     if ops.current_bn_repeat() > 1:      # k identical forwards in one: the closed form of k momentum updates
         mom = 1.0 - (1.0 - mom) ** ops.current_bn_repeat()
     return ops.NormActFn.apply(x, res, m.weight, m.bias, a, gs, bs, m.running_mean, m.running_var, "batch", m.training,
-                               act, float(m.eps), mom, stats, groups)
+                               act, float(m.eps), mom, stats, groups, None, bool(offer_tail))
 
 
 def fixed_padding_extents(kernel_size, rate):
@@ -266,10 +268,12 @@ class Block(BGModule):
             rep.append(SeparableConv2d_same(planes, planes, 3, stride=1))
         self.rep = nn.Sequential(*rep)
 
-    def forward(self, inp, pre_activated=False, activate_output=False):
+    def forward(self, inp, pre_activated=False, activate_output=False, sole_consumer=False):
         """inp: NHWC.  pre_activated: the caller already applied this block's
         leading LeakyReLU (fused into the producer).  activate_output: also apply
-        the NEXT block's leading LeakyReLU to the sum."""
+        the NEXT block's leading LeakyReLU to the sum.  sole_consumer: the caller passes the result to exactly one
+        consumer, the next Block (whose fork backward may then take over the first half of this Block's final BatchNorm
+        backward: ops.NormTail)."""
         a = inp
         if self.start_with_relu and not pre_activated:
             a = ops.leaky_relu(inp)
@@ -282,7 +286,7 @@ class Block(BGModule):
             # backward adds the skip path's gradient inside the depthwise data-gradient kernel
             arena = self.arena()
             h, a_skip = ops.ForkDwConv3x3Fn.apply(a, first.conv1.weight, arena, arena.by_param[id(first.conv1.weight)],
-                                                  first.conv1.dilation[0])
+                                                  first.conv1.dilation[0], getattr(a, "_bg_tail", None))
             dw_done = True
         else:
             a_main, a_skip = ops.fork(a, 2)
@@ -324,7 +328,7 @@ class Block(BGModule):
         else:
             s = a_skip
         if last_norm is not None:
-            return conv_norm(self, last_sep, last_norm, h, res=s, act=activate_output, skip_dw=dw_done)
+            return conv_norm(self, last_sep, last_norm, h, res=s, act=activate_output, skip_dw=dw_done, offer_tail=sole_consumer)
         return ops.add(h, s, act=activate_output)
 
 
@@ -383,8 +387,8 @@ class Xception(BGModule):
         if want_low:
             # = leaky_relu(block1 output): the tensor block2 activates in place (deeplab.py:241-243)
             low, x = ops.fork(x, 2)
-        for i in range(2, 20):
-            x = getattr(self, f"block{i}")(x, pre_activated=True, activate_output=True)
+        for i in range(2, 20):   # each of these outputs goes to the next Block and nowhere else
+            x = getattr(self, f"block{i}")(x, pre_activated=True, activate_output=True, sole_consumer=True)
         # data parallel: once backward has come back to here, the gradients of the exit flow and of everything registered
         # after this Xception (ASPP, decoder / the critic's head: ~48 % of the generator's bytes) are final and their
         # all-reduce starts under the middle and entry flow's backward (ops.GradMilestoneFn; no-op on one GPU)

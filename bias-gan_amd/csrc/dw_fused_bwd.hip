@@ -316,7 +316,311 @@ void fb_launch(const DwFusedParams& P, hipStream_t st) {
     hipLaunchKernelGGL((dw_bwd_fused_kernel<WG, D>), dim3((unsigned)(P.slabs * P.bps)), dim3(FB_THREADS), FbGeo<D>::LDS_BYTES, st, P);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fork at a Block's input (deeplab.py:134-141), backward, in ONE pass (round 4).  The Block's input a0 = y_k -- the
+// activated output of the previous Block's final [BatchNorm + residual + LeakyReLU] node -- feeds the first depthwise
+// convolution and the skip path.  Round 3 ran, per Block: bg_dwconv3x3_bwd_data_add (read dA, read the skip gradient, write
+// d(a0)), bg_dwconv3x3_bwd_weight (read dA, read a0) and, for the PRODUCER of a0, the first pass of its BatchNorm
+// backward (read d(a0), read y_k, read z) plus a second output of its apply pass (write d(a0) * act'(y_k) as the residual
+// gradient): 8 + 2 tensor passes.  Here, per pixel q and channel:
+//     t        = bf16( sum_t dA[q + (1-t)] w[t] + skip[q] )                what bg_dwconv3x3_bwd_data_add stores
+//     gout[q]  = t * act'(a0[q])                                           the gradient BEHIND the producer's activation
+//     dW[t]   += a0[q] dA[q + (1-t)]
+//     s1      += gout,  s2 += gout * xhat,   xhat = (z[q] - mean) rstd     the producer's BatchNorm-backward sums
+// 5 tensor passes (dA + halo from L2, a0, skip, z; gout).  The producer's apply pass then reads gout as an already
+// activated gradient (act = 0), and its residual gradient IS gout (no copy).  Stride 1, dilation 1 (the entry, middle and
+// exit Blocks at os = 16), bf16.  Geometry: tiles of 4 rows x 24 columns x 64 channels, all four inputs staged by LDS-DMA
+// into one of two buffers (dA with its halo as 6 rows x 32 pixels, the three others as 4 x 24), 3 pixel iterations per tile.
+struct DwForkParams {
+    const bf16_t* g;      // dA: gradient w.r.t. the depthwise output [N, H, W, C], pixel stride ldg
+    const bf16_t* x;      // a0: the Block's activated input, pixel stride ldx
+    const bf16_t* skip;   // gradient w.r.t. the skip alias of a0, pixel stride lds
+    const bf16_t* z;      // the producer BatchNorm's input, pixel stride ldz
+    const bf16_t* w;      // [3][3][C]
+    const float* mean;    // producer BatchNorm, [groups][C]
+    const float* rstd;
+    bf16_t* gout;         // out, pixel stride ldo
+    float* dw;            // [3][3][C] fp32, accumulated (NULL: weights frozen)
+    double* s1;
+    double* s2;
+    int N, H, W, C, ldg, ldx, lds, ldz, ldo, ipg;
+    float slope;          // act'(y) for y < 0 (1: the producer has no activation)
+    int slabs, tiles_h, tiles_w, tiles, bps;
+};
+
+struct FkGeo {
+    static constexpr int R = 4, D = 1;
+    static constexpr int THP = R + 2 * D;
+    static constexpr int DPIX = THP * FB_PITCH;      // 192 staged dA pixels
+    static constexpr int ZPIX = R * FB_TW;           // 96 staged pixels of each of a0 / skip / z
+    static constexpr int NPD = DPIX / 8, NPZ = ZPIX / 8;             // 24 and 12 eight-pixel pieces
+    static constexpr int SLOTS_A = NPD / FB_NWAVE;                    // 3: wave w issues dA pieces w, w + 8, w + 16
+    static constexpr int SLOTS_Z = (NPZ + FB_NWAVE - 1) / FB_NWAVE;   // 2 per part: pieces w and (w < 4) w + 8
+    static constexpr int SLOTS = SLOTS_A + 3 * SLOTS_Z;               // 9 per wave and tile
+    static constexpr int ITERS = 3;
+    static constexpr int PPI = SLOTS / ITERS;                         // 3 issued per pixel iteration
+    static constexpr int BUF_BYTES = (DPIX + 3 * ZPIX) * 128;         // 61 440
+    static constexpr int RED_BYTES = 2 * FB_PL * FB_SLAB * 4;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES + RED_BYTES + FB_NWAVE * 1024;
+    static_assert(NPD % FB_NWAVE == 0 && SLOTS % ITERS == 0, "slot arithmetic");
+    static_assert(LDS_BYTES <= 160 * 1024 && 9 * FB_PL * FB_SLAB * 4 <= 2 * BUF_BYTES, "LDS budget");
+};
+
+template <bool WG>
+__global__ __launch_bounds__(FB_THREADS) void dw_fork_bwd_kernel(DwForkParams P) {
+    typedef FkGeo G;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    extern __shared__ __align__(16) char fb_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    {   // blocks sharing id % 8 share an XCD: a contiguous range of (tile, slab) per XCD (halo pixels and the 128-byte pieces
+        // of one pixel range meet in one L2)
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = lin & 7, k = lin >> 3;
+        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int slab = lin % P.slabs, tb = lin / P.slabs;
+    const int it = tid & (FB_ITEMS - 1), pl = tid >> 4;
+    const int pr = pl >> 3, pc = pl & 7;
+    const int c0 = slab * FB_SLAB + it * 4;
+    const bool c_ok = c0 < P.C;
+    const int per_img = P.tiles_h * P.tiles_w;
+
+    float wf[9][4], dwa[9][4], a1[4], a2[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        s16x4 v = {0, 0, 0, 0};
+        if (c_ok) v = *reinterpret_cast<const s16x4*>(P.w + (long long)t * P.C + c0);
+        unpack4(v, wf[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dwa[t][e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a1[e] = a2[e] = 0.f;
+    float rs[4], mo[4];
+    int cur_g = -1;
+    char* const buf0 = fb_smem;
+    float* const red_s = reinterpret_cast<float*>(fb_smem + 2 * G::BUF_BYTES);
+    char* const dump = fb_smem + 2 * G::BUF_BYTES + G::RED_BYTES + wave * 1024;
+
+    auto flush_stats = [&](int g) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red_s[(0 * FB_PL + pl) * FB_SLAB + it * 4 + e] = a1[e];
+            red_s[(1 * FB_PL + pl) * FB_SLAB + it * 4 + e] = a2[e];
+            a1[e] = a2[e] = 0.f;
+        }
+        __syncthreads();
+        if (tid < 2 * FB_SLAB) {
+            const int s = tid >> 6, ch = tid & 63;
+            float acc = 0.f;
+#pragma unroll
+            for (int y = 0; y < FB_PL; ++y) acc += red_s[(s * FB_PL + y) * FB_SLAB + ch];
+            const int c = slab * FB_SLAB + ch;
+            if (c < P.C) atomicAdd((s ? P.s2 : P.s1) + (long long)g * P.C + c, (double)acc);
+        }
+    };
+
+    // ---- staging (the scheme of dw_bwd_fused_kernel): piece = 8 pixels x 128 B = one wave instruction; every call issues
+    // exactly one -- a dead slot fetches out of range into the wave's dump area -- so the operation count is static.
+    const int lp = lane >> 3, piece = lane & 7;
+    const bool ch_ok = slab * FB_SLAB + piece * 8 < P.C;
+    const int cb = slab * FB_SLAB + piece * 8;
+    const int lane_g = ch_ok ? (lp * P.ldg + cb) * 2 : FB_OOB;
+    const int lane_x = ch_ok ? (lp * P.ldx + cb) * 2 : FB_OOB;
+    const int lane_s = ch_ok ? (lp * P.lds + cb) * 2 : FB_OOB;
+    const int lane_z = ch_ok ? (lp * P.ldz + cb) * 2 : FB_OOB;
+    const char* d_bg = reinterpret_cast<const char*>(P.g);
+    const char* d_bx = reinterpret_cast<const char*>(P.x);
+    const char* d_bs = reinterpret_cast<const char*>(P.skip);
+    const char* d_bz = reinterpret_cast<const char*>(P.z);
+    int d_row0 = 0, d_col0 = 0;
+    bool d_on = false;
+    char* d_dst = buf0;
+    auto dma_begin = [&](int tile_, char* dst) {
+        const int n = tile_ / per_img, rem = tile_ - n * per_img;
+        const int th = rem / P.tiles_w, tw = rem - th * P.tiles_w;
+        d_row0 = th * G::R; d_col0 = tw * FB_TW;
+        const long long pix = ((long long)n * P.H + d_row0) * P.W + d_col0;
+        d_bg = reinterpret_cast<const char*>(P.g) + (pix - P.W - 1) * P.ldg * 2;     // (row0 - 1, col0 - 1)
+        d_bx = reinterpret_cast<const char*>(P.x) + pix * P.ldx * 2;
+        d_bs = reinterpret_cast<const char*>(P.skip) + pix * P.lds * 2;
+        d_bz = reinterpret_cast<const char*>(P.z) + pix * P.ldz * 2;
+        d_dst = dst;
+        d_on = true;
+    };
+    int wv = wave;
+    auto dma_a = [&](int j) {        // dA piece wv + 8 j: row k / 4, pixels (k % 4) * 8 ..
+        const int k = wv + FB_NWAVE * j;
+        const int tr = k >> 2, px = (k & 3) * 8;
+        const char* base = d_bg + (tr * P.W + px) * P.ldg * 2;
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+        const bool ok = d_on && (unsigned)(d_row0 - 1 + tr) < (unsigned)P.H && (unsigned)(d_col0 - 1 + px + lp) < (unsigned)P.W;
+        fb_dma16(rsd, d_on ? d_dst + k * 1024 : dump, ok ? lane_g : FB_OOB);
+    };
+    auto dma_p = [&](int part, int j) {   // piece wv + 8 j of part 0 (a0) / 1 (skip) / 2 (z): row k / 3, pixels (k % 3) * 8 ..
+        const int k = wv + FB_NWAVE * j;
+        const int tr = (k * 43) >> 7, px = (k - tr * 3) * 8;
+        const bool live = d_on && k < G::NPZ;
+        const char* b = part == 0 ? d_bx : part == 1 ? d_bs : d_bz;
+        const int ld = part == 0 ? P.ldx : part == 1 ? P.lds : P.ldz;
+        const int lo = part == 0 ? lane_x : part == 1 ? lane_s : lane_z;
+        const char* base = b + (tr * P.W + px) * ld * 2;
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+        const bool ok = live && d_row0 + tr < P.H && d_col0 + px + lp < P.W;
+        fb_dma16(rsd, live ? d_dst + (G::NPD + part * G::NPZ + k) * 1024 : dump, ok ? lo : FB_OOB);
+    };
+    auto dma_slot = [&](int s_) {    // slot 0 .. 8 of a tile (compile-time at every call site)
+        if (s_ < G::SLOTS_A) dma_a(s_);
+        else dma_p((s_ - G::SLOTS_A) / G::SLOTS_Z, (s_ - G::SLOTS_A) % G::SLOTS_Z);
+    };
+
+    int tile = tb, cur = 0;
+    if (tile < P.tiles) {
+        dma_begin(tile, buf0);
+#pragma unroll
+        for (int s_ = 0; s_ < G::SLOTS; ++s_) dma_slot(s_);
+    }
+    const int lds_tap = ((pr + 2) * FB_PITCH + pc + 2) * 128 + it * 8;
+    const int lds_p = G::DPIX * 128 + (pr * FB_TW + pc) * 128 + it * 8;
+    for (; tile < P.tiles; tile += P.bps) {
+        const int n = tile / per_img, rem = tile - n * per_img;
+        const int th = rem / P.tiles_w, tw = rem - th * P.tiles_w;
+        const int g = n / P.ipg;
+        if (g != cur_g) {   // block-uniform
+            if (cur_g >= 0) flush_stats(cur_g);
+            cur_g = g;
+            if (c_ok) {
+                const long long o = (long long)g * P.C + c0;
+                const f32x4 m = *reinterpret_cast<const f32x4*>(P.mean + o), r = *reinterpret_cast<const f32x4*>(P.rstd + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rs[e] = r[e]; mo[e] = -m[e] * r[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rs[e] = 0.f; mo[e] = 0.f; }
+            }
+        }
+        const int row0 = th * G::R, col0 = tw * FB_TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        asm volatile("" : "+s"(wv));
+        const char* tbuf = buf0 + cur * G::BUF_BYTES;
+        const bool has_next = tile + P.bps < P.tiles;
+        if (has_next) dma_begin(tile + P.bps, buf0 + (cur ^ 1) * G::BUF_BYTES);
+        else d_on = false;
+        const long long tile_pix0 = ((long long)n * P.H + row0) * P.W + col0;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(P.gout + tile_pix0 * P.ldo, 0, 0x7fffffff, 0x00020000);
+        const char* tap0 = tbuf + lds_tap;
+        const char* p0 = tbuf + lds_p;
+        const bool r_ok = c_ok && pr < P.H - row0;
+        const int cmax = P.W - col0 - pc;
+        const int d_thread = ((pr * P.W + pc) * P.ldo + c0) * 2;
+#pragma unroll
+        for (int cg = 0; cg < 3; ++cg) {
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = r_ok && cg * 8 < cmax;
+#pragma unroll
+            for (int q = 0; q < G::PPI; ++q) dma_slot(cg * G::PPI + q);
+            float av[4], sk[4], zv[4];
+            unpack4(*reinterpret_cast<const s16x4*>(p0 + cg * 8 * 128), av);                       // a0 (zero outside the image)
+            unpack4(*reinterpret_cast<const s16x4*>(p0 + (G::ZPIX + cg * 8) * 128), sk);
+            unpack4(*reinterpret_cast<const s16x4*>(p0 + (2 * G::ZPIX + cg * 8) * 128), zv);
+            float dacc[4] = {sk[0], sk[1], sk[2], sk[3]};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int tr = t / 3, tc = t - tr * 3;
+                float v[4];
+                unpack4(*reinterpret_cast<const s16x4*>(tap0 + ((-tr) * FB_PITCH + cg * 8 - tc) * 128), v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dacc[e] = fmaf(v[e], wf[t][e], dacc[e]);
+                    if (WG) dwa[t][e] = fmaf(av[e], v[e], dwa[t][e]);
+                }
+            }
+            // t as the separate data-gradient kernel stores it, then the producer's activation derivative from its output
+            const bf16x4 tb_ = {(bf16_t)dacc[0], (bf16_t)dacc[1], (bf16_t)dacc[2], (bf16_t)dacc[3]};
+            float tr_[4], gg[4];
+            unpack4(__builtin_bit_cast(s16x4, tb_), tr_);
+            const float m1 = ok ? 1.f : 0.f, ms = m1 * P.slope;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gg[e] = tr_[e] * (av[e] > 0.f ? m1 : ms);      // y > 0 ? 1 : slope, as the reduce / apply kernels
+            const bf16x4 gb = {(bf16_t)gg[0], (bf16_t)gg[1], (bf16_t)gg[2], (bf16_t)gg[3]};
+            const int doff = ok ? d_thread + cg * 8 * P.ldo * 2 : FB_OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, gb), rd, doff, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a1[e] += gg[e];
+                a2[e] = fmaf(gg[e], fmaf(zv[e], rs[e], mo[e]), a2[e]);
+            }
+        }
+        cur ^= 1;
+    }
+    if (cur_g >= 0) flush_stats(cur_g);
+    if (WG) {
+        float* red = reinterpret_cast<float*>(fb_smem);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(t * FB_PL + pl) * FB_SLAB + it * 4 + e] = dwa[t][e];
+        __syncthreads();
+        for (int j = tid; j < 9 * FB_SLAB; j += FB_THREADS) {
+            const int t = j >> 6, ch = j & 63;
+            float acc = 0.f;
+#pragma unroll
+            for (int y = 0; y < FB_PL; ++y) acc += red[(t * FB_PL + y) * FB_SLAB + ch];
+            const int c = slab * FB_SLAB + ch;
+            if (c < P.C) atomicAdd(P.dw + (long long)t * P.C + c, acc);
+        }
+    }
+}
+
+template <bool WG>
+void fk_launch(const DwForkParams& P, hipStream_t st) {
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_fork_bwd_kernel<WG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL((dw_fork_bwd_kernel<WG>), dim3((unsigned)(P.slabs * P.bps)), dim3(FB_THREADS), FkGeo::LDS_BYTES, st, P);
+}
+
 }  // namespace
+
+extern "C" int bg_dwconv3x3_bwd_fork(const bg_dwconv_desc* d, const void* dy, const void* w, const void* a0, const void* skip,
+                                     int32_t ldskip, const void* z, int32_t ldz, const float* mean, const float* rstd,
+                                     int32_t groups, int32_t act, void* gout, int32_t ldgout, float* dw, double* s1, double* s2,
+                                     void* stream) {
+    BG_CHECK_ARG(d && d->dtype == BG_BF16, "bg_dwconv3x3_bwd_fork: bf16 tensors only (the fp32 path runs the separate kernels)");
+    BG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 8 == 0 && d->Ho == d->H && d->Wo == d->W && d->stride == 1 &&
+                     d->dil == 1, "bg_dwconv3x3_bwd_fork: stride 1, dilation 1, C a multiple of 8");
+    BG_CHECK_ARG(d->ldx >= d->C && d->ldy >= d->C && ldskip >= d->C && ldz >= d->C && ldgout >= d->C && d->ldx % 8 == 0 &&
+                     d->ldy % 8 == 0 && ldskip % 8 == 0 && ldz % 8 == 0 && ldgout % 8 == 0, "bg_dwconv3x3_bwd_fork: bad pixel strides");
+    BG_CHECK_ARG(dy && w && a0 && skip && z && mean && rstd && gout && s1 && s2 && aligned16(dy) && aligned16(w) && aligned16(a0) &&
+                     aligned16(skip) && aligned16(z) && aligned16(gout) && aligned16(mean) && aligned16(rstd),
+                 "bg_dwconv3x3_bwd_fork: null/unaligned pointer");
+    BG_CHECK_ARG(groups >= 1 && d->N % groups == 0 && act >= 0 && act <= 2, "bg_dwconv3x3_bwd_fork: groups / act");
+    const int ldmax = std::max(std::max(std::max(d->ldx, d->ldy), std::max(ldskip, ldz)), ldgout);
+    BG_CHECK_ARG((long long)d->H * d->W * ldmax * 2 < (1LL << 31), "bg_dwconv3x3_bwd_fork: an image beyond 2 GiB");
+    DwForkParams P{};
+    P.g = (const bf16_t*)dy; P.x = (const bf16_t*)a0; P.skip = (const bf16_t*)skip; P.z = (const bf16_t*)z; P.w = (const bf16_t*)w;
+    P.mean = mean; P.rstd = rstd; P.gout = (bf16_t*)gout; P.dw = dw; P.s1 = s1; P.s2 = s2;
+    P.N = d->N; P.H = d->H; P.W = d->W; P.C = d->C; P.ldg = d->ldy; P.ldx = d->ldx; P.lds = ldskip; P.ldz = ldz; P.ldo = ldgout;
+    P.ipg = d->N / groups;
+    P.slope = act == 0 ? 1.f : act == 2 ? 0.f : LRELU_SLOPE;
+    P.slabs = (d->C + FB_SLAB - 1) / FB_SLAB;
+    P.tiles_h = (P.H + FkGeo::R - 1) / FkGeo::R;
+    P.tiles_w = (P.W + FB_TW - 1) / FB_TW;
+    P.tiles = P.N * P.tiles_h * P.tiles_w;
+    static const int target = getenv("BGAMD_FB_BLOCKS") ? atoi(getenv("BGAMD_FB_BLOCKS")) : 256;   // one workgroup per CU walking its tiles
+    P.bps = std::max(1, std::min(P.tiles, target / P.slabs));
+    hipStream_t st = (hipStream_t)stream;
+    if (dw) fk_launch<true>(P, st); else fk_launch<false>(P, st);
+    BG_CHECK_LAUNCH("dw_fork_bwd_kernel");
+    return BG_OK;
+}
 
 extern "C" int bg_dwconv3x3_bwd_fused(const bg_dwconv_desc* d, const void* dy, const void* w, const void* x, const float* scale,
                                       const float* shift, const float* mean, const float* rstd, int32_t groups, int32_t act,

@@ -748,14 +748,20 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
     Stride 1, dilation 1 or 2."""
 
     @staticmethod
-    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, dil):
+    def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, dil, tail=None):
+        """tail: the ops.NormTail of the node that produced x (it offers the first half of its backward), or None."""
         x = nhwc(x)
         n, h, w, c = x.shape
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         y = new_act(n, h, w, c, x.dtype, x.device)
         desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
         L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
-        if weight.requires_grad:
+        ctx.tail = None
+        if (tail is not None and _FORK_FUSED and dil == 1 and x.dtype == torch.bfloat16 and ctx.needs_input_grad[0]
+                and tail.y_ptr == x.data_ptr() and h * w * max(ld_of(x), ld_of(y), ld_of(tail.x)) * 2 < (1 << 31)):
+            ctx.tail = tail
+            tail.claimed += 1
+        if weight.requires_grad or ctx.tail is not None:
             ctx.save_for_backward(x)
         ctx.meta = (arena, wslot, dil, tuple(x.shape), x.dtype, x.device)
         return y, x.view_as(x)
@@ -770,6 +776,24 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
         if gskip is not None:
             gskip = nhwc(gskip)
         dx = None
+        tail = ctx.tail
+        if tail is not None and tail.claimed == 1 and ctx.needs_input_grad[0] and g is not None and gskip is not None:
+            # ONE pass: depthwise data gradient + skip gradient, the producer's activation derivative, the depthwise weight
+            # gradient and the producer's two BatchNorm-backward sums (bg_dwconv3x3_bwd_fork); the producer's backward finds
+            # the sums in its tail and treats the gradient as already activated
+            (x,) = ctx.saved_tensors
+            want_dw = ctx.needs_input_grad[1]
+            if want_dw:
+                arena.ensure_grad(wslot)
+            gout = new_act(n, h, w, c, xdtype, xdev)
+            sums = _f64(2, tail.groups, c, device=xdev)
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+            L.call("bg_dwconv3x3_bwd_fork", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), gskip.data_ptr(),
+                   ld_of(gskip), tail.x.data_ptr(), ld_of(tail.x), tail.mean.data_ptr(), tail.rstd.data_ptr(), tail.groups,
+                   tail.act, gout.data_ptr(), ld_of(gout), arena.grad_ptr(wslot) if want_dw else None, sums[0].data_ptr(),
+                   sums[1].data_ptr())
+            tail.sums, tail.gout = sums, gout
+            return gout, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             if g is None:
                 dx = gskip
@@ -786,7 +810,23 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
             arena.ensure_grad(wslot)
             desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
             wgrad_call(xdev, (x, g), "bg_dwconv3x3_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot))
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
+
+
+class NormTail:
+    """What a [BatchNorm (batch statistics) -> (+ residual) -> activation] node offers the SOLE consumer of its output so
+    that the consumer's backward can also do the first half of this node's backward (ForkDwConv3x3Fn / bg_dwconv3x3_bwd_fork):
+    the BatchNorm's input and saved statistics going out; the two sums and the already-activated gradient coming back.
+    The producer only attaches it where the caller guarantees a single consumer (Block.forward(sole_consumer=True):
+    Xception chains its Blocks that way) -- a second consumer's gradient would be added to an activated one."""
+    __slots__ = ("x", "mean", "rstd", "groups", "act", "y_ptr", "claimed", "sums", "gout")
+
+    def __init__(self, x, mean, rstd, groups, act, y):
+        self.x, self.mean, self.rstd, self.groups, self.act, self.y_ptr = x, mean, rstd, groups, act, y.data_ptr()
+        self.claimed, self.sums, self.gout = 0, None, None
+
+
+_FORK_FUSED = _os.environ.get("BGAMD_FORK_FUSED", "1") != "0"   # A/B switch: 0 = data_add + weight gradient + reduce as separate launches
 
 
 def fork_dw_ok(conv1) -> bool:
@@ -856,7 +896,7 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, arena, gslot, bslot, rmean, rvar, kind, training, act, eps, momentum,
-                pre_stats=None, bn_groups=1, inst_groups=None):
+                pre_stats=None, bn_groups=1, inst_groups=None, offer_tail=False):
         """bn_groups: 'batch' statistics are taken separately over that many equal sub-batches (see
         batch_groups()).  pre_stats: fp64 [2, groups, C] sums already produced by the convolution's epilogue
         (bg_conv2d_fwd_stats); skips the separate statistics pass."""
@@ -898,6 +938,10 @@ class NormActFn(torch.autograd.Function):
                    0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.meta = (arena, gslot, bslot, kind, use_batch_stats, int(act), groups, res is not None)
+        ctx.tail = None
+        if (offer_tail and _FORK_FUSED and kind == "batch" and use_batch_stats and x.dtype == torch.bfloat16
+                and ctx.needs_input_grad[0] and ctx.q_site is None and not getattr(arena, "fp8", False)):
+            ctx.tail = y._bg_tail = NormTail(x, mean, rstd, groups, int(act), y)
         return y
 
     @staticmethod
@@ -910,16 +954,36 @@ class NormActFn(torch.autograd.Function):
         rows = n * h * w
         need_dx = ctx.needs_input_grad[0]
         need_res = has_res and ctx.needs_input_grad[1]
+        tail = ctx.tail
+        if tail is not None and tail.sums is not None:
+            # the consumer's backward (bg_dwconv3x3_bwd_fork) already multiplied the gradient by act'(y) and accumulated
+            # sum g, sum g * xhat: no reduce pass, the apply pass runs without an activation, the residual gradient IS g
+            if g.data_ptr() != tail.gout.data_ptr():
+                raise RuntimeError("bias_gan_amd: a fused fork backward needs its producer's output to have ONE consumer "
+                                   "(the incoming gradient is not the tensor the fork's backward wrote)")
+            s, tail.sums, tail.gout = tail.sums, None, None
+            dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
+            want_affine_grads = gslot is not None and gslot.param.requires_grad
+            if need_dx or want_affine_grads:
+                dg = db = None
+                if want_affine_grads:
+                    arena.ensure_grad(gslot)
+                    arena.ensure_grad(bslot)
+                    dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
+                L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), None, 0, x.data_ptr(), ld_of(x),
+                       s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot), arena.master_ptr(bslot), mean.data_ptr(),
+                       rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), None, 0, rows, c, groups, 0)
+            return (dx, g if need_res else None) + (None,) * 16
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
         if kind == "identity":
             if dx is None and dres is None:
-                return (None,) * 17
+                return (None,) * 18
             # dx and dres are the same tensor values: write once, alias
             out = dx if dx is not None else dres
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None,
                    out.data_ptr(), ld_of(out), None, 0, rows, c, groups, act)
-            return (out if need_dx else None, out if need_res else None) + (None,) * 15
+            return (out if need_dx else None, out if need_res else None) + (None,) * 16
         want_affine_grads = gslot is not None and gslot.param.requires_grad
         gptr = None if gslot is None else arena.master_ptr(gslot)
         bptr = None if bslot is None else arena.master_ptr(bslot)
@@ -944,7 +1008,7 @@ class NormActFn(torch.autograd.Function):
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
-        return (dx, dres) + (None,) * 15
+        return (dx, dres) + (None,) * 16
 
 
 _DW_FUSED_BWD = _os.environ.get("BGAMD_DW_FUSED_BWD", "1") != "0"   # A/B switch: 0 = the three separate backward kernels

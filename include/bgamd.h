@@ -225,6 +225,27 @@ int bg_dwconv3x3_bwd_fused(const bg_dwconv_desc* d, const void* dy, const void* 
                            const float* shift, const float* mean, const float* rstd, int32_t groups, int32_t act, void* da,
                            int32_t ldda, float* dw, double* s1, double* s2, void* stream);
 
+/* The fork at a Block's input, backward, in ONE pass (bf16; round 4).  Reference: the Block of
+ * architecture/gpsro/deeplab.py:90-143 feeds its input `inp` to `rep` (first op: the depthwise convolution of
+ * SeparableConv2d_same, :75-87) and to the skip path (:134-141); autograd then adds the two gradients and continues into
+ * the producer of `inp`, the previous Block's [BatchNorm -> (+ residual) -> LeakyReLU].  This entry point does, from
+ *   dy   gradient w.r.t. the depthwise output (pixel stride d->ldy),
+ *   a0   the Block's activated input (pixel stride d->ldx),
+ *   skip gradient w.r.t. the skip alias of a0 (pixel stride ldskip),
+ *   z    the producer BatchNorm's input, mean / rstd its saved fp32 [groups, C] statistics (pixel stride ldz):
+ *   t    = bf16(depthwise data gradient of dy + skip)          -- what bg_dwconv3x3_bwd_data_add stores
+ *   gout = t * act'(a0)      (act 1: a0 > 0 ? 1 : 0.2, act 2: a0 > 0 ? 1 : 0, act 0: 1)   -- the gradient BEHIND the
+ *                              producer's activation: its bg_norm_act_bwd_apply_stats then runs with act = 0 and its
+ *                              residual gradient is gout itself
+ *   dw  += depthwise weight gradient (a0 against dy; NULL: weights frozen)
+ *   s1 / s2 (fp64 [groups, C], caller zeroes) += sum gout, sum gout * (z - mean) * rstd   -- what bg_norm_act_bwd_reduce
+ *                              adds for the producer.
+ * Replaces bg_dwconv3x3_bwd_data_add + bg_dwconv3x3_bwd_weight + bg_norm_act_bwd_reduce and the residual-gradient output
+ * of the apply pass: 10 tensor passes -> 5.  Stride 1, dilation 1. */
+int bg_dwconv3x3_bwd_fork(const bg_dwconv_desc* d, const void* dy, const void* w, const void* a0, const void* skip,
+                          int32_t ldskip, const void* z, int32_t ldz, const float* mean, const float* rstd, int32_t groups,
+                          int32_t act, void* gout, int32_t ldgout, float* dw, double* s1, double* s2, void* stream);
+
 /* ---------------------------------------------------------------------------
  * 3-D DeepLab GAN path (architecture/gpsro/deeplab3d.py).  A volume [N,D,H,W,C] is the
  * NHWC tensor [N*D,H,W,C]; every entry point above applies to it as it stands.  The third dimension adds:

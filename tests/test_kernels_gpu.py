@@ -1206,3 +1206,72 @@ def test_dwconv_bwd_fused_matches_the_three_kernels(case, with_dw):
            gamma.data_ptr(), beta.data_ptr(), rows, cp, groups, act, s1c.data_ptr(), s2c.data_ptr())
     assert_close(s1b.cpu(), s1c.cpu(), 2e-5, "sum g vs the reduction of the same da")
     assert_close(s2b.cpu(), s2c.cpu(), 2e-5, "sum g * xhat vs the reduction of the same da")
+
+
+@pytest.mark.parametrize("with_dw", [True, False])
+@pytest.mark.parametrize("case", [(2, 9, 7, 728, 1, 1), (4, 13, 18, 16, 2, 1), (2, 6, 5, 40, 1, 0), (2, 11, 50, 264, 1, 2), (2, 72, 48, 728, 1, 1),
+                                  (2, 37, 101, 136, 2, 1), (3, 5, 130, 72, 3, 1), (4, 72, 48, 728, 2, 1), (1, 3, 5, 8, 1, 1)])
+def test_dwconv_bwd_fork_matches_the_kernels_it_replaces(case, with_dw):
+    """bg_dwconv3x3_bwd_fork (the fork at a Block's input, backward, in one pass: deeplab.py:134-141) against the launches
+    it replaces on the same bf16 tensors -- bg_dwconv3x3_bwd_data_add (t = dwT(dy) + skip), bg_dwconv3x3_bwd_weight (a0 against
+    dy), bg_norm_act_bwd_reduce with y = a0 (sum g, sum g * xhat, g = t * act'(a0)) and the residual-gradient output of
+    bg_norm_act_bwd_apply (gout = t * act'(a0)) -- and against torch in fp32.  t rounds like the separate kernel's (the same
+    fp32 terms in another order: <= 1 bf16 ulp on a few elements); the sums are taken from the UNROUNDED product like the
+    reduce kernel's.  Last case: a map smaller than one tile (every range of the staging descriptors starts or ends outside)."""
+    n, h, w, c, groups, act = case
+    dtype = torch.bfloat16
+    cp = up(c, dtype)
+    a0 = rnd((n, c, h, w), 81, dtype, 1.5)
+    z = (rnd((n, c, h, w), 82, dtype, 2.0) + 0.3).to(dtype).float()
+    wt = rnd((c, 1, 3, 3), 83, dtype, 0.3)
+    go = rnd((n, c, h, w), 84, dtype)
+    sk = rnd((n, c, h, w), 85, dtype, 0.7)
+    ld, lds_, ldz, ldo = cp + 8, cp + 16, cp + 24, cp + 32
+    (ab, av), (gb, gv) = to_nhwc(a0, dtype, ld, 8), to_nhwc(go, dtype, ld, 8)
+    (sb, sv), (zb, zv) = to_nhwc(sk, dtype, lds_, 8), to_nhwc(z, dtype, ldz, 8)
+    wk = torch.zeros(3, 3, cp, dtype=dtype, device=DEV)
+    wk[:, :, :c] = wt[:, 0].permute(1, 2, 0).to(dtype).to(DEV)
+    rows, dtc = n * h * w, L.dt(dtype)
+    f32 = lambda *s_: torch.zeros(*s_, device=DEV)  # noqa: E731
+    f64 = lambda *s_: torch.zeros(*s_, device=DEV, dtype=torch.float64)  # noqa: E731
+    s, ss = f64(groups, cp), f64(groups, cp)
+    L.call("bg_norm_stats", dtc, zv.data_ptr(), rows, cp, ldz, groups, s.data_ptr(), ss.data_ptr())
+    gamma, beta = torch.ones(cp, device=DEV), torch.zeros(cp, device=DEV)
+    mean, rstd, scale, shift = f32(groups, cp), f32(groups, cp), f32(groups, cp), f32(groups, cp)
+    L.call("bg_norm_finalize_affine", s.data_ptr(), ss.data_ptr(), rows // groups, groups, cp, gamma.data_ptr(), beta.data_ptr(),
+           1e-5, 0.1, None, None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    # ---- the separate launches
+    t0 = torch.full((n, h, w, ldo), 3.0, dtype=dtype, device=DEV)
+    L.call("bg_dwconv3x3_bwd_data_add", L.DwDesc(dtc, n, h, w, cp, h, w, 1, 1, ldo, ld), gv.data_ptr(), wk.data_ptr(), sv.data_ptr(),
+           lds_, t0.data_ptr())
+    dw0 = f32(3, 3, cp)
+    L.call("bg_dwconv3x3_bwd_weight", L.DwDesc(dtc, n, h, w, cp, h, w, 1, 1, ld, ld), av.data_ptr(), gv.data_ptr(), dw0.data_ptr())
+    s1a, s2a = f64(groups, cp), f64(groups, cp)
+    L.call("bg_norm_act_bwd_reduce", dtc, t0.data_ptr(), ldo, av.data_ptr() if act else None, ld, zv.data_ptr(), ldz, mean.data_ptr(),
+           rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, cp, groups, act, s1a.data_ptr(), s2a.data_ptr())
+    # ---- the fused kernel
+    g1 = torch.full((n, h, w, ldo), 3.0, dtype=dtype, device=DEV)
+    dw1 = f32(3, 3, cp)
+    s1b, s2b = f64(groups, cp), f64(groups, cp)
+    L.call("bg_dwconv3x3_bwd_fork", L.DwDesc(dtc, n, h, w, cp, h, w, 1, 1, ld, ld), gv.data_ptr(), wk.data_ptr(), av.data_ptr(),
+           sv.data_ptr(), lds_, zv.data_ptr(), ldz, mean.data_ptr(), rstd.data_ptr(), groups, act, g1.data_ptr(), ldo,
+           dw1.data_ptr() if with_dw else None, s1b.data_ptr(), s2b.data_ptr())
+    torch.cuda.synchronize()
+    assert (g1[..., cp:].float() == 3.0).all(), "lanes beyond C were written"
+    slope = 1.0 if act == 0 else 0.0 if act == 2 else 0.2
+    fac = torch.where(av[..., :cp].float() > 0, 1.0, slope)
+    want = (t0[..., :cp].float() * fac).to(dtype).float().cpu()          # what the apply pass would have written as the residual gradient
+    got = g1[..., :cp].float().cpu()
+    assert (want - got).abs().max().item() <= 2.0 ** -7 * want.abs().max().item(), (want - got).abs().max().item()
+    assert ((want != got).float().mean().item()) < 2e-2, "more than 2 % of the elements round differently"
+    ref_t = torch.nn.grad.conv2d_input((n, c, h + 2, w + 2), wt, go, 1, 0, 1, groups=c)[:, :, 1:1 + h, 1:1 + w] + sk
+    ref = ref_t * torch.where(a0 > 0, 1.0, slope)
+    assert_close(from_nhwc(g1, c), ref, 1e-2, "fork gradient vs torch")
+    if with_dw:
+        assert_close(dw1.cpu(), dw0.cpu(), 2e-5, "fork depthwise weight gradient")
+        ref_dw = torch.nn.grad.conv2d_weight(torch.nn.functional.pad(a0, (1, 1, 1, 1)), (c, 1, 3, 3), go, 1, 0, 1, groups=c)
+        assert_close(dw1[:, :, :c].permute(2, 0, 1).cpu(), ref_dw[:, 0], 1e-2, "fork depthwise weight gradient vs torch")
+    else:
+        assert (dw1 == 0).all()
+    assert_close(s1b.cpu(), s1a.cpu(), 2e-4, "sum g")
+    assert_close(s2b.cpu(), s2a.cpu(), 2e-4, "sum g * xhat")
