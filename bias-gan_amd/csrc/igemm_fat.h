@@ -127,6 +127,39 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst, 16, voffset, 0, 0, 0);
 }
 
+#ifdef ABL_FAT_PRODUCER
+// Ablation (scripts/ablate_fat.sh, not shipped): a synthetic stand-in for an in-kernel depthwise PRODUCER of the B operand
+// (the fused [BatchNorm + LeakyReLU -> depthwise -> pointwise] forward unit of DESIGN.md 7), to MEASURE how much of its
+// instruction stream hides in the shadow of the MFMAs before the real kernel is written: per MFMA group ABL_FAT_PRODUCER
+// vector instructions in the producer's mix (packed FMAs, bf16 unpacks, max, cvt) on eight scratch registers and
+// ABL_FAT_PRODUCER_LDS 16-byte LDS reads of the stage being consumed.  Results are discarded.
+#ifndef ABL_FAT_PRODUCER_LDS
+#define ABL_FAT_PRODUCER_LDS 0
+#endif
+typedef __attribute__((ext_vector_type(2))) float abl_f32x2;
+struct AblRegs { abl_f32x2 p0, p1, p2; unsigned u0, u1, u2; };
+__device__ __forceinline__ void abl_init(AblRegs& r, int lane) {
+    r.p0 = abl_f32x2{0.5f, 0.25f}; r.p1 = abl_f32x2{1e-3f, 2e-3f}; r.p2 = abl_f32x2{3e-3f, 1e-3f};
+    r.u0 = 0x3f803f00u + lane; r.u1 = r.u2 = 0;
+}
+__device__ __forceinline__ void abl_producer(AblRegs& r, const char* lds) {
+#pragma unroll
+    for (int i = 0; i < ABL_FAT_PRODUCER_LDS; ++i) {
+        i32x4 t;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"((int)(size_t)lds), "n"(i * 1024));
+    }
+#pragma unroll
+    for (int i = 0; i < ABL_FAT_PRODUCER / 8; ++i) {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0\n\tv_and_b32 %4, 0xffff0000, %3\n\tv_pk_fma_f32 %1, %2, %0, %1\n\tv_lshlrev_b32 %5, 16, %3\n\t"
+                     "v_pk_fma_f32 %2, %0, %1, %2\n\tv_max_f32 %3, %4, %5\n\tv_pk_mul_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %3, %4, %5"
+                     : "+v"(r.p0), "+v"(r.p1), "+v"(r.p2), "+v"(r.u0), "+v"(r.u1), "+v"(r.u2));
+    }
+}
+__device__ __forceinline__ void abl_sink(const AblRegs& r, double* where) {   // keeps the scratch registers alive; never true
+    if (r.p0[0] + r.p1[1] + r.p2[0] == 12345.678f && r.u0 == 7u) where[0] = 1.0;
+}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -652,6 +685,10 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
     const int r16 = lane & 15, q = lane >> 4;
     const int rowA = wave_c * MI * 16, rowB = wave_p * NJ * 16;
     int buf = 0, nbuf = DIST % NBUF;
+#ifdef ABL_FAT_PRODUCER
+    AblRegs abl;
+    abl_init(abl, lane);
+#endif
     // A real s_waitcnt lgkmcnt(0) the compiler can SEE (encoding: vmcnt 63, expcnt 7, lgkmcnt 0): a scalar load still pending on
     // the loop's entry edge makes its waitcnt pass treat lgkmcnt as out-of-order at the loop header, and then the first LDS
     // wait of EVERY iteration is lgkmcnt(0) -- all nine fragment reads before the first MFMA -- instead of a count.
@@ -746,6 +783,9 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
                             if ((ks * MI + i) * PPG + e < GROUP) piece(nbuf, (ks * MI + i) * PPG + e);
                     }
                     const bool carry = i == MI - 1 && ks + 1 < NKS;     // this group hands over to the next substep
+#ifdef ABL_FAT_PRODUCER
+                    abl_producer(abl, sB + lane * 16);
+#endif
                     bf16x8 an = a;
 #ifdef ABL_FAT_NO_A
                     an = b[(i + 1) % NJ];
@@ -793,6 +833,9 @@ __global__ __launch_bounds__(512) void gemm_conv_fat_kernel(GemmConvParams P) {
     }
     BG_STAMP(3);
     BG_STAMP_CYC(7);
+#ifdef ABL_FAT_PRODUCER
+    abl_sink(abl, P.stat_sum);
+#endif
     typedef typename OutOf<T>::type TO;
     if constexpr (sizeof(TO) == 2) conv_epilogue_fat_ct<TO, MI, NJ, WM, WN>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);
     else conv_epilogue_fat<TO, MI, NJ, WM, WN>(P, acc, p_base, rows_valid, grp, c_base, wave_c, wave_p, lane, smem);

@@ -295,6 +295,9 @@ class GANTrainer:
                 import warnings
                 warnings.warn(f"whole-step hipGraph capture failed ({type(err).__name__}: {err}); this configuration stays eager")
                 torch.cuda.synchronize()
+                # the host RNG stream advances ONCE per iteration: the eager re-run takes the labels / eta drawn above
+                if labels is None and lab is not None:
+                    labels = (lf, lr_, swap)
                 return self._eager_step(inputs, outputs_real, masks, labels, eta)
         else:
             for o in opts:

@@ -133,7 +133,7 @@ class InfillGANTrainer:
                 import warnings
                 warnings.warn(f"whole-step hipGraph capture failed ({type(err).__name__}: {err}); this configuration stays eager")
                 torch.cuda.synchronize()
-                return self._eager_step(inputs_raw, outputs_real, masks_raw, noise, labels, None)
+                return self._eager_step(inputs_raw, outputs_real, masks_raw, noise, labels if labels is not None else (lf, lr_, swap), None)
         else:
             for o in opts:
                 o.prepare_replay()       # step count, lr and bias corrections of THIS step -> device

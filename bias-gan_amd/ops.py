@@ -330,6 +330,28 @@ def grad_milestone(x, arena: Arena, first_tail_params):
 
 
 # ------------------------------------------------------------------ layout boundary
+# Module boundaries are NCHW fp32 like the reference's (Generator.forward -> Discriminator.forward, train_gan.py:252-254,
+# 275-276).  Where a boundary tensor is handed straight from one of our modules to another, the NHWC compute-dtype bytes
+# it was converted FROM still exist: FromInternal leaves a note on its result (the internal tensor, the tensor's version),
+# and ToInternal / ToInternalCat take the internal bytes instead of converting the fp32 copy back (bf16 -> fp32 -> bf16 is
+# the identity, so the values are the same bits).  The same note serves an input that is converted twice in one
+# iteration (the generator's two forwards on one batch).  A tensor written after the note was made has a new version and
+# is converted as usual.  BGAMD_NO_HANDOVER=1 disables.
+_HANDOVER = _os.environ.get("BGAMD_NO_HANDOVER") is None
+
+
+def _internal_of(x: torch.Tensor, cp: int, dtype: torch.dtype):
+    """The NHWC tensor `x` (NCHW fp32) was converted from or to, if it is still valid for (cp, dtype)."""
+    note = getattr(x, "_bg_internal", None) if _HANDOVER else None
+    if note is None:
+        return None
+    t, version, ptr = note
+    n, c, h, w = x.shape
+    if version != x._version or ptr != x.data_ptr() or t.dtype != dtype or tuple(t.shape) != (n, h, w, cp):
+        return None
+    return t
+
+
 class ToInternal(torch.autograd.Function):
     """NCHW fp32 (module boundary, as the reference passes tensors) -> NHWC compute dtype."""
 
@@ -339,7 +361,12 @@ class ToInternal(torch.autograd.Function):
             x = x.float()
         n, c, h, w = x.shape
         ctx.c = c
+        src = _internal_of(x, cp, dtype)
+        if src is not None:
+            return src.detach()      # the same bytes under a fresh tensor (this node's output must not carry another node's history)
         y = new_act(n, h, w, cp, dtype, x.device)
+        if _HANDOVER and not x.requires_grad:
+            x._bg_internal = (y, x._version, x.data_ptr())    # a second conversion of this batch (G's two forwards) reuses it
         xl = x.permute(0, 2, 3, 1)
         if c == cp and xl.is_contiguous() and x.data_ptr() % 16 == 0:
             # the caller's tensor is channels-last in memory (HWC files read by the staging ring, stacked: the layout
@@ -373,8 +400,13 @@ class ToInternalCat(torch.autograd.Function):
         y = new_act(sum(ctx.ns), h, w, cp, dtype, xs[0].device)
         n0 = 0
         for x in xs:
-            x = x.contiguous()
-            L.call("bg_nchw_to_nhwc", L.dt(dtype), x.data_ptr(), y[n0:].data_ptr(), x.shape[0], c, h * w, cp, ld_of(y))
+            src = _internal_of(x, cp, dtype)
+            if src is not None:      # handed over by one of our modules: copy its NHWC rows instead of transposing the fp32 copy
+                L.call("bg_cast_rows", L.dt(dtype), L.dt(dtype), src.data_ptr(), ld_of(src), y[n0:].data_ptr(), ld_of(y),
+                       x.shape[0] * h * w, cp)
+            else:
+                x = x.contiguous()
+                L.call("bg_nchw_to_nhwc", L.dt(dtype), x.data_ptr(), y[n0:].data_ptr(), x.shape[0], c, h * w, cp, ld_of(y))
             n0 += x.shape[0]
         return y
 
@@ -404,6 +436,8 @@ class FromInternal(torch.autograd.Function):
         ctx.cp, ctx.dtype = cp, x.dtype
         y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
         L.call("bg_nhwc_to_nchw", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), n, c, h * w)
+        if _HANDOVER:   # (channels beyond c are zero lanes in every internal activation: DESIGN.md 1, test_parity_gpu "pad lanes")
+            y._bg_internal = (x.detach(), y._version, y.data_ptr())
         return y
 
     @staticmethod
@@ -444,6 +478,14 @@ def _splitk_finish(ws, y):
 
 # ---- fp8 operand path (BASELINE.json configs[4]; include/bgamd.h "fp8 operand path") --------------------------------
 _FP8_MIN_WORK = int(_os.environ.get("BGAMD_FP8_MIN_WORK", "1500"))
+
+
+def set_fp8_min_work(v: int) -> int:
+    """Threshold of fp8_layer_ok (taps x channels of the other GEMM side from which a layer's operands are quantised even
+    without a producer-written copy); 0 puts EVERY eligible layer on fp8 operands.  Returns the previous value."""
+    global _FP8_MIN_WORK
+    old, _FP8_MIN_WORK = _FP8_MIN_WORK, int(v)
+    return old
 
 
 def fp8_layer_ok(arena: Arena, wslot: ParamSlot, kh, kw, grad: bool = False, prequantised: bool = False) -> bool:

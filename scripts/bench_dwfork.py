@@ -51,5 +51,5 @@ for N in batches:
         tn = timeit(lambda: fk(None))
         mb = rows * c * 2e-6
         print(f"b{N:2d} C{c:5d} {h:3d}x{w:3d} ({mb:6.1f} MB/tensor): data_add {t1:6.1f} + wgrad {t2:6.1f} + reduce {t3:6.1f} + apply {t4:6.1f} = "
-              f"{t1 + t2 + t3 + t4:6.1f} us | fork {tf:6.1f} ({5 * mb / tf * 1e-3:5.2f} TB/s) + apply {t5:6.1f} = {tf + t5:6.1f} us x{(t1 + t2 + t3 + t4) / (tf + t5):.2f} | "
+              f"{t1 + t2 + t3 + t4:6.1f} us | fork {tf:6.1f} ({5 * mb / tf:5.2f} TB/s) + apply {t5:6.1f} = {tf + t5:6.1f} us x{(t1 + t2 + t3 + t4) / (tf + t5):.2f} | "
               f"frozen weights: {t1 + t3 + t4:6.1f} vs {tn + t5:6.1f} (fork {tn:6.1f}) x{(t1 + t3 + t4) / (tn + t5):.2f}", flush=True)

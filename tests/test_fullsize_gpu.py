@@ -128,7 +128,9 @@ def test_c5_full_size_step_fp8_vs_oracle():
     fake_ref = fake_ref.clone()
     del st
     res = {}
-    for dtype in (torch.bfloat16, torch.float8_e4m3fn):
+    from bias_gan_amd import ops as _ops
+    for tag, dtype, min_work in (("bf16", torch.bfloat16, None), ("fp8", torch.float8_e4m3fn, None), ("fp8_all", torch.float8_e4m3fn, 0)):
+        prev = _ops.set_fp8_min_work(min_work) if min_work is not None else None    # 0: EVERY eligible layer on fp8 operands
         G = dxg.Generator(c, c, "Interpolate", "Uniform", 0, normalizer=nn.BatchNorm2d, compute_dtype=dtype)
         D = dxg.Discriminator(c, normalizer=nn.BatchNorm2d, input_size=(h, w), compute_dtype=dtype)
         G.load_state_dict(orc.fill_state(gspec, 1)), D.load_state_dict(orc.fill_state(dspec, 2))
@@ -142,16 +144,22 @@ def test_c5_full_size_step_fp8_vs_oracle():
             fake = G(xd).float().cpu()
         e_fake = float(((fake - fake_ref).double().pow(2).mean().sqrt() / fake_ref.double().pow(2).mean().sqrt()))
         d_loss, g_loss = tr.step(xd, yd, labels=labels)
-        res[dtype] = (d_loss.item(), g_loss.item(), e_fake)
-        print(f"c5 2304x1536x32 N=2 {dtype}: generator output rms-rel {e_fake:.2e} | d_loss {res[dtype][0]:.5f} (oracle {d_ref:.5f}, "
-              f"rel {_rel(res[dtype][0], d_ref):.2e})  g_loss {res[dtype][1]:.5f} (oracle {g_ref:.5f}, rel {_rel(res[dtype][1], g_ref):.2e})")
+        res[tag] = (d_loss.item(), g_loss.item(), e_fake)
+        print(f"c5 2304x1536x32 N=2 {tag}: generator output rms-rel {e_fake:.2e} | d_loss {res[tag][0]:.5f} (oracle {d_ref:.5f}, "
+              f"rel {_rel(res[tag][0], d_ref):.2e})  g_loss {res[tag][1]:.5f} (oracle {g_ref:.5f}, rel {_rel(res[tag][1], g_ref):.2e})")
         del tr, G, D, fake
         torch.cuda.empty_cache()
-    b16, f8 = res[torch.bfloat16], res[torch.float8_e4m3fn]
-    assert all(np.isfinite(v) for v in f8)
+        if prev is not None:
+            _ops.set_fp8_min_work(prev)
+    b16, f8, f8a = res["bf16"], res["fp8"], res["fp8_all"]
+    assert all(np.isfinite(v) for v in f8 + f8a)
     assert _rel(b16[0], d_ref) <= 2e-1 and _rel(b16[1], g_ref) <= 2e-1 and b16[2] <= 2e-1     # measured 1.0e-2, 9.1e-3
     # fp8 with the default layer rule (ops.fp8_layer_ok: operands in fp8 where the quantisation pass pays -- the exit flow,
     # the ASPP, the decoder's 3 x 3 layers), 2 x measured: generator output 1.54e-1 (bf16: 1.18e-1), d_loss 1.25e-1,
     # g_loss 1.09e-1.  With EVERY eligible layer on fp8 operands (BGAMD_FP8_MIN_WORK=0) the same run measured d_loss
     # 3.0e-1, g_loss 5.5e-1: the docstring's accumulation through ~70 layers.
     assert _rel(f8[0], d_ref) <= 2.5e-1 and _rel(f8[1], g_ref) <= 2.2e-1 and f8[2] <= 3.1e-1
+    # the hard case pinned, not just described: every eligible layer on fp8 operands; bounds 2 x the
+    # round-3 measurement (d_loss 3.0e-1, g_loss 5.5e-1; generator output bounded like the default rule's, x 2).  End to end
+    # the fp8 path is LOOSE by construction -- parity of the path rests on the kernel- and Block-level pins of tests/test_fp8_gpu.py.
+    assert _rel(f8a[0], d_ref) <= 6.0e-1 and _rel(f8a[1], g_ref) <= 1.1 and f8a[2] <= 6.2e-1

@@ -1116,7 +1116,7 @@ def test_failed_step_capture_falls_back_without_advancing_the_host_state(monkeyp
         for k in ("lrs", "t", "step", "nbt"):
             assert e[k] == g[k], (lr, k, e[k], g[k])
         assert e["step"] == 5 and e["t"] == (5, 5) and e["nbt"] == (10, 15)
-        assert g["calls"] == e["calls"] + 1            # the aborted capture reached the criterion once more; nothing else ran twice
+        assert g["calls"] == e["calls"]                # the aborted capture died INSIDE the criterion (.item() raised before the append)
         if lr == 0.0:
             for i, (a, b) in enumerate(zip(e["losses"], g["losses"])):
                 assert abs(a[0] - b[0]) <= 2e-5 * abs(a[0]) + 1e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]), (i, a, b)
@@ -1307,7 +1307,9 @@ def test_reuse_g_forward_reproduces_the_two_forward_step(monkeypatch, dtype):
 
     a, b = run(False), run(True)
     print(f"{dtype}: two forwards d {a[0]:.6f} g {a[1]:.6f} | one forward d {b[0]:.6f} g {b[1]:.6f}; layout-in launches {a[3]} vs {b[3]}")
-    assert b[3] < a[3], "the generator's input conversion should run once less"
+    # (since round 4 the two-forward step converts its input batch once as well: ops.ToInternal reuses the NHWC copy of an
+    # unchanged input tensor -- the hand-over note of ops._internal_of)
+    assert b[3] <= a[3], "the generator's input conversion must not run more often"
     # the two runs differ by the arrival order of D's float-atomic weight gradients (fp32 path: per-layer kernel), which the
     # G-step's loss sees through D's update: measured 7e-7 ... 1.6e-6 run to run (fp32), bound at 3x
     tol = 5e-6 if dtype == F32 else 2e-5
