@@ -51,8 +51,70 @@ def _is_nhwc(t: torch.Tensor, vec: int) -> bool:
     return True
 
 
+# ---------------------------------------------------------------- image-chunked producer -> consumer pairs
+# The entry flow's and the decoder's activations are 450 - 900 MB at 1152 x 768, batch 8: a tensor one kernel writes has left
+# the 256 MB Infinity Cache long before the next kernel reads it, and every such hand-over is a full HBM read (these layers
+# are HBM-bound: half of the step's time sits in launches of >= 400 MB).  Where a producer's ONLY reader is the next launch
+# and nothing batch-global lies between them (no BatchNorm statistics), the pair is run image chunk by image chunk --
+# producer(chunk), consumer(chunk) -- so that the consumer finds the chunk in the cache: the producer does not launch, it
+# leaves a Deferred note on its (allocated, still empty) output; a consumer that knows the protocol (Conv2dFn) walks the
+# chunks; every other consumer runs the whole producer first (nhwc() does that: every Function passes its inputs through it).
+# Same kernels, same arithmetic, per-image launches: results are bit-identical up to the order of statistic atomics.
+_CHUNK_MB = int(_os.environ.get("BGAMD_CHUNK_MB", "96"))     # target chunk size; 0 switches the chunked schedule off
+
+
+class Deferred:
+    """run(n0, n1) launches the producer for images [n0, n1) of the tensor the note hangs on."""
+    __slots__ = ("run", "n", "groups", "chunk", "done")
+
+    def __init__(self, run, n, groups, chunk):
+        self.run, self.n, self.groups, self.chunk, self.done = run, n, groups, chunk, False
+
+
+def chunk_images(n: int, groups: int, bytes_per_image: int) -> int:
+    """Images per chunk for an intermediate tensor of n images, or 0 when the tensor is small enough to survive in the cache
+    whole (or the schedule is off).  A chunk never straddles two statistic groups."""
+    if _CHUNK_MB <= 0 or n * bytes_per_image <= 2 * _CHUNK_MB * (1 << 20):
+        return 0
+    per_group = n // max(groups, 1)
+    c = max(1, min(per_group, (_CHUNK_MB << 20) // max(bytes_per_image, 1)))
+    while per_group % c:
+        c -= 1
+    return c if c < n else 0
+
+
+_DEFERRED = {}     # data_ptr -> (weakref of the tensor the note was made for, Deferred): finds the note through a view as well
+
+
+def defer_on(y: torch.Tensor, d: Deferred):
+    import weakref
+    y._bg_defer = d
+    _DEFERRED[y.data_ptr()] = (weakref.ref(y), d)
+
+
+def take_deferred(t: torch.Tensor):
+    """The pending Deferred of `t` (by attribute, or by address for a view of the tensor it was made for), removed from the
+    registry; None if there is none."""
+    d = getattr(t, "_bg_defer", None)
+    if d is not None:
+        t._bg_defer = None
+    if _DEFERRED:
+        ent = _DEFERRED.pop(t.data_ptr(), None)
+        if ent is not None and d is None and ent[0]() is not None:     # (a dead weakref: the tensor died unread, the address was reused)
+            d = ent[1]
+    return d if d is not None and not d.done else None
+
+
+def flush_deferred(t: torch.Tensor):
+    d = take_deferred(t)
+    if d is not None:
+        d.done = True
+        d.run(0, d.n)
+
+
 def nhwc(t: torch.Tensor) -> torch.Tensor:
     """Return `t` if the kernels can address it as NHWC rows, else a packed copy."""
+    flush_deferred(t)
     vec = 8 if t.dtype == torch.bfloat16 else 4
     if _is_nhwc(t, vec):
         return t
@@ -570,7 +632,16 @@ class Conv2dFn(torch.autograd.Function):
                 stats=None):
         """stats: optional zeroed fp64 [2, Cout_phys]; the kernel adds sum(y), sum(y^2) of the stored
         outputs to it from its accumulators (the batch statistics of the BatchNorm that follows)."""
-        x = nhwc(x)
+        dfr = take_deferred(x)
+        if dfr is not None and (bslot is not None or getattr(arena, "fp8", False)
+                                or not _is_nhwc(x, 8 if x.dtype == torch.bfloat16 else 4)):
+            dfr.done = True
+            dfr.run(0, dfr.n)     # a consumer the chunked schedule does not cover: the whole producer now
+            dfr = None
+        if dfr is not None:
+            dfr.done = True       # this consumer walks the chunks itself
+        else:
+            x = nhwc(x)
         n, h, w, cin = x.shape
         kp, kh, kw, cp = wslot.phys_shape
         assert cin == cp, f"conv expects {cp} input channels (padded), got {cin}"
@@ -578,6 +649,25 @@ class Conv2dFn(torch.autograd.Function):
         wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
+        if dfr is not None:
+            # producer(chunk), this convolution(chunk): the chunk is read out of the Infinity Cache instead of HBM
+            es = x.element_size()
+            sgroups = 1 if stats is None else stats.shape[1]
+            for n0 in range(0, n, dfr.chunk):
+                n1 = min(n, n0 + dfr.chunk)
+                dfr.run(n0, n1)
+                dc = L.ConvDesc(L.dt(x.dtype), n1 - n0, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
+                xp, yp = x.data_ptr() + n0 * h * w * ld_of(x) * es, y.data_ptr() + n0 * ho * wo * ld_of(y) * es
+                if stats is not None:
+                    g_ = n0 // (n // sgroups)             # a chunk lies inside one statistic group (chunk_images)
+                    L.call("bg_conv2d_fwd_stats", dc, xp, arena.weight_ptr(wslot), yp, stats[0][g_].data_ptr(),
+                           stats[1][g_].data_ptr(), 1)
+                else:
+                    L.call("bg_conv2d_fwd", dc, xp, arena.weight_ptr(wslot), None, yp)
+            if weight.requires_grad:
+                ctx.save_for_backward(x)
+            ctx.meta = (arena, wslot, bslot, stride, pad, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
+            return y
         splits = splitk_plan(n * ho * wo, kp, cin, kh, kw, x.dtype) if bslot is None else 0
         xq = fp8_copy_of(x)
         use8 = x.dtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw, prequantised=xq is not None)
@@ -745,6 +835,27 @@ def avgpool2x2(x, p: int):
     return AvgPool2x2Fn.apply(x, int(p))
 
 
+def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups):
+    """bg_dwconv3x3_fwd now, or -- for a tensor too large to survive in the Infinity Cache -- as a Deferred note on y that
+    the pointwise convolution reading y runs chunk by chunk (see the chunked-schedule comment at the top of this file)."""
+    dt, es = L.dt(x.dtype), x.element_size()
+    ldx, ldy = ld_of(x), ld_of(y)
+    if n % max(groups, 1):
+        groups = 1
+    ch = chunk_images(n, groups, ho * wo * ldy * es) if _is_nhwc(y, 8 if x.dtype == torch.bfloat16 else 4) else 0
+
+    yp = y.data_ptr()      # (the note hangs on y: the closure must not hold y itself -- a reference cycle would keep 450 MB alive)
+
+    def run(n0, n1):
+        d = L.DwDesc(dt, n1 - n0, h, w, c, ho, wo, stride, dil, ldx, ldy)
+        L.call("bg_dwconv3x3_fwd", d, x.data_ptr() + n0 * h * w * ldx * es, wptr, yp + n0 * ho * wo * ldy * es)
+
+    if ch:
+        defer_on(y, Deferred(run, n, groups, ch))
+    else:
+        run(0, n)
+
+
 class DwConv3x3Fn(torch.autograd.Function):
     """Depthwise 3x3 of SeparableConv2d_same with fixed_padding folded in (bg_dwconv3x3_*)."""
 
@@ -755,8 +866,7 @@ class DwConv3x3Fn(torch.autograd.Function):
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         ho, wo = -(-h // stride), -(-w // stride)
         y = new_act(n, ho, wo, c, x.dtype, x.device)
-        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(y))
-        L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
+        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, ho, wo, stride, dil, current_bn_groups())
         if weight.requires_grad:
             ctx.save_for_backward(x)
         ctx.meta = (arena, wslot, stride, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
@@ -796,8 +906,7 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
         n, h, w, c = x.shape
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         y = new_act(n, h, w, c, x.dtype, x.device)
-        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
-        L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
+        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, h, w, 1, dil, current_bn_groups())
         ctx.tail = None
         if (tail is not None and _FORK_FUSED and dil == 1 and x.dtype == torch.bfloat16 and ctx.needs_input_grad[0]
                 and tail.y_ptr == x.data_ptr() and h * w * max(ld_of(x), ld_of(y), ld_of(tail.x)) * 2 < (1 << 31)):
@@ -1086,7 +1195,24 @@ class NormActDwConvFn(torch.autograd.Function):
         upd = rmean is not None
         y = new_act(n, h, w, c, x.dtype, dev)
         desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
-        if _FOLD_FINALIZE and c <= 4096:
+        es = x.element_size()
+        ch = chunk_images(n, groups, h * w * ld_of(y) * es) if _is_nhwc(y, 8 if x.dtype == torch.bfloat16 else 4) else 0
+        if ch:
+            # too large to survive in the Infinity Cache: the statistics are finalised now, the depthwise launches are left to
+            # the pointwise convolution that reads y, chunk by chunk (Deferred; same arithmetic as the folded launch below)
+            L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
+                   arena.master_ptr(gslot), arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None,
+                   rvar.data_ptr() if upd else None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            ldx, ldy, wptr, ipg, yp = ld_of(x), ld_of(y), arena.weight_ptr(wslot), n // groups, y.data_ptr()
+
+            def run(n0, n1, x=x):     # (holds x, scale, shift -- not y, on which the note hangs)
+                g_ = n0 // ipg
+                d_ = L.DwDesc(dt, n1 - n0, h, w, c, h, w, 1, dil, ldx, ldy)
+                L.call("bg_dwconv3x3_fwd_pre", d_, x.data_ptr() + n0 * h * w * ldx * es, scale[g_].data_ptr(), shift[g_].data_ptr(), 1,
+                       int(act), wptr, yp + n0 * h * w * ldy * es)
+
+            defer_on(y, Deferred(run, n, groups, ch))
+        elif _FOLD_FINALIZE and c <= 4096:
             # the depthwise kernel finalises the statistics itself (no launch between the GEMM and it)
             L.call("bg_dwconv3x3_fwd_pre_stats", desc, x.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot),
                    arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None,
