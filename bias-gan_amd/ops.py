@@ -86,6 +86,16 @@ def chunk_images(n: int, groups: int, bytes_per_image: int) -> int:
 _DEFERRED = {}     # data_ptr -> (weakref of the tensor the note was made for, Deferred): finds the note through a view as well
 
 
+def chain_deferred(up, run, n, groups, chunk):
+    """A Deferred for `run`, behind the pending producer `up` of its input (None: none): the chain runs chunk by chunk,
+    upstream first.  The chunk size is the upstream's (one schedule per chain)."""
+    if up is None:
+        return Deferred(run, n, groups, chunk)
+    up.done = True
+    urun = up.run
+    return Deferred(lambda n0, n1: (urun(n0, n1), run(n0, n1))[1], n, groups, up.chunk)
+
+
 def defer_on(y: torch.Tensor, d: Deferred):
     import weakref
     y._bg_defer = d
@@ -355,6 +365,7 @@ class GradMilestoneFn(torch.autograd.Function):
         # freezes the critic around its autograd.grad) grad_milestone() inserts no node, and needs_input_grad[1] is False
         # for a node created while the probe did not require a gradient
         ctx.arena, ctx.off = arena, off
+        flush_deferred(x)
         # a network may be called more than once before one backward pass (D(real) and D(fake)): the tail is final when the
         # LAST of these nodes has run, so they are counted (reset by FlatAllReduce.finish())
         arena.ddp.ms_pending += 1
@@ -835,7 +846,7 @@ def avgpool2x2(x, p: int):
     return AvgPool2x2Fn.apply(x, int(p))
 
 
-def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups):
+def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups, up=None):
     """bg_dwconv3x3_fwd now, or -- for a tensor too large to survive in the Infinity Cache -- as a Deferred note on y that
     the pointwise convolution reading y runs chunk by chunk (see the chunked-schedule comment at the top of this file)."""
     dt, es = L.dt(x.dtype), x.element_size()
@@ -843,6 +854,10 @@ def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups):
     if n % max(groups, 1):
         groups = 1
     ch = chunk_images(n, groups, ho * wo * ldy * es) if _is_nhwc(y, 8 if x.dtype == torch.bfloat16 else 4) else 0
+    if up is not None and not ch:      # the input's producer is pending but this output is not chunk-worthy: produce the input now
+        up.done = True
+        up.run(0, up.n)
+        up = None
 
     yp = y.data_ptr()      # (the note hangs on y: the closure must not hold y itself -- a reference cycle would keep 450 MB alive)
 
@@ -851,9 +866,19 @@ def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups):
         L.call("bg_dwconv3x3_fwd", d, x.data_ptr() + n0 * h * w * ldx * es, wptr, yp + n0 * ho * wo * ldy * es)
 
     if ch:
-        defer_on(y, Deferred(run, n, groups, ch))
+        defer_on(y, chain_deferred(up, run, n, groups, ch))
     else:
         run(0, n)
+
+
+def _take_upstream(x):
+    """The pending producer of x if x can be addressed as it stands (else it is produced now by nhwc())."""
+    up = take_deferred(x)
+    if up is not None and not _is_nhwc(x, 8 if x.dtype == torch.bfloat16 else 4):
+        up.done = True
+        up.run(0, up.n)
+        up = None
+    return up
 
 
 class DwConv3x3Fn(torch.autograd.Function):
@@ -861,12 +886,13 @@ class DwConv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, stride, dil):
+        up = _take_upstream(x)
         x = nhwc(x)
         n, h, w, c = x.shape
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         ho, wo = -(-h // stride), -(-w // stride)
         y = new_act(n, ho, wo, c, x.dtype, x.device)
-        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, ho, wo, stride, dil, current_bn_groups())
+        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, ho, wo, stride, dil, current_bn_groups(), up)
         if weight.requires_grad:
             ctx.save_for_backward(x)
         ctx.meta = (arena, wslot, stride, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
@@ -902,11 +928,12 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, dil, tail=None):
         """tail: the ops.NormTail of the node that produced x (it offers the first half of its backward), or None."""
+        up = _take_upstream(x)
         x = nhwc(x)
         n, h, w, c = x.shape
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         y = new_act(n, h, w, c, x.dtype, x.device)
-        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, h, w, 1, dil, current_bn_groups())
+        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, h, w, 1, dil, current_bn_groups(), up)
         ctx.tail = None
         if (tail is not None and _FORK_FUSED and dil == 1 and x.dtype == torch.bfloat16 and ctx.needs_input_grad[0]
                 and tail.y_ptr == x.data_ptr() and h * w * max(ld_of(x), ld_of(y), ld_of(tail.x)) * 2 < (1 << 31)):
@@ -1074,10 +1101,31 @@ class NormActFn(torch.autograd.Function):
                 L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
             mean, rstd = _e32(2, groups, c, device=dev).unbind(0)
             upd = kind == "batch" and rmean is not None
-            # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
-            L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
-                   momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
+            es = x.element_size()
+            vec_ = 8 if x.dtype == torch.bfloat16 else 4
+            ch = (chunk_images(n, groups, h * w * ld_of(y) * es)
+                  if kind == "batch" and _is_nhwc(y, vec_) and _is_nhwc(x, vec_) and (res is None or _is_nhwc(res, vec_)) else 0)
+            if ch:
+                # too large to survive in the Infinity Cache until its reader runs: statistics finalised now, the apply pass
+                # left to that reader, chunk by chunk (Deferred; the arithmetic of the folded launch below)
+                scale, shift = _e32(2, groups, c, device=dev).unbind(0)
+                L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, bptr, eps,
+                       momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
+                       rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+                ldx, ldy, ldr, ipg, yp, hw = ld_of(x), ld_of(y), 0 if res is None else ld_of(res), n // groups, y.data_ptr(), h * w
+
+                def run(n0, n1, x=x, res=res):    # (holds x, res, scale, shift -- not y, on which the note hangs)
+                    g_ = n0 // ipg
+                    L.call("bg_norm_act_fwd", dt, x.data_ptr() + n0 * hw * ldx * es, ldx, scale[g_].data_ptr(), shift[g_].data_ptr(),
+                           None if res is None else res.data_ptr() + n0 * hw * ldr * es, ldr, yp + n0 * hw * ldy * es, ldy,
+                           (n1 - n0) * hw, c, 1, int(act))
+
+                defer_on(y, Deferred(run, n, groups, ch))
+            else:
+                # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
+                L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
+                       momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
+                       rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
         else:
             if kind != "identity":  # BatchNorm in eval mode: affine from the running statistics
                 mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
@@ -1297,6 +1345,7 @@ class ForkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k: int):
         ctx.k = k
+        flush_deferred(x)      # (several readers: the chunked schedule ends here)
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod
