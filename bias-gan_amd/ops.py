@@ -61,14 +61,27 @@ def _is_nhwc(t: torch.Tensor, vec: int) -> bool:
 # chunks; every other consumer runs the whole producer first (nhwc() does that: every Function passes its inputs through it).
 # Same kernels, same arithmetic, per-image launches: results are bit-identical up to the order of statistic atomics.
 _CHUNK_MB = int(_os.environ.get("BGAMD_CHUNK_MB", "96"))     # target chunk size; 0 switches the chunked schedule off
+_CHUNK_BWD = _os.environ.get("BGAMD_CHUNK_BWD", "1") != "0"   # ... its backward chains (apply -> data gradient -> depthwise backward)
 
 
 class Deferred:
-    """run(n0, n1) launches the producer for images [n0, n1) of the tensor the note hangs on."""
-    __slots__ = ("run", "n", "groups", "chunk", "done")
+    """run(n0, n1) launches the producer for images [n0, n1) of the tensor the note hangs on; `after` are launches that
+    need the WHOLE tensor (a grouped / per-layer weight gradient of a convolution in the chain) and run once the last
+    chunk is out: finish()."""
+    __slots__ = ("run", "n", "groups", "chunk", "done", "after", "tag")
 
-    def __init__(self, run, n, groups, chunk):
-        self.run, self.n, self.groups, self.chunk, self.done = run, n, groups, chunk, False
+    def __init__(self, run, n, groups, chunk, tag=""):
+        self.run, self.n, self.groups, self.chunk, self.done, self.after, self.tag = run, n, groups, chunk, False, [], tag
+
+    def finish(self):
+        todo, self.after = self.after, []
+        for f in todo:
+            f()
+
+    def run_all(self):
+        self.done = True
+        self.run(0, self.n)
+        self.finish()
 
 
 def chunk_images(n: int, groups: int, bytes_per_image: int) -> int:
@@ -86,14 +99,16 @@ def chunk_images(n: int, groups: int, bytes_per_image: int) -> int:
 _DEFERRED = {}     # data_ptr -> (weakref of the tensor the note was made for, Deferred): finds the note through a view as well
 
 
-def chain_deferred(up, run, n, groups, chunk):
+def chain_deferred(up, run, n, groups, chunk, tag=""):
     """A Deferred for `run`, behind the pending producer `up` of its input (None: none): the chain runs chunk by chunk,
     upstream first.  The chunk size is the upstream's (one schedule per chain)."""
     if up is None:
-        return Deferred(run, n, groups, chunk)
+        return Deferred(run, n, groups, chunk, tag)
     up.done = True
     urun = up.run
-    return Deferred(lambda n0, n1: (urun(n0, n1), run(n0, n1))[1], n, groups, up.chunk)
+    d = Deferred(lambda n0, n1: (urun(n0, n1), run(n0, n1))[1], n, groups, up.chunk, up.tag + " > " + tag)
+    d.after, up.after = up.after, []
+    return d
 
 
 def defer_on(y: torch.Tensor, d: Deferred):
@@ -118,8 +133,7 @@ def take_deferred(t: torch.Tensor):
 def flush_deferred(t: torch.Tensor):
     d = take_deferred(t)
     if d is not None:
-        d.done = True
-        d.run(0, d.n)
+        d.run_all()
 
 
 def nhwc(t: torch.Tensor) -> torch.Tensor:
@@ -646,8 +660,7 @@ class Conv2dFn(torch.autograd.Function):
         dfr = take_deferred(x)
         if dfr is not None and (bslot is not None or getattr(arena, "fp8", False)
                                 or not _is_nhwc(x, 8 if x.dtype == torch.bfloat16 else 4)):
-            dfr.done = True
-            dfr.run(0, dfr.n)     # a consumer the chunked schedule does not cover: the whole producer now
+            dfr.run_all()         # a consumer the chunked schedule does not cover: the whole producer now
             dfr = None
         if dfr is not None:
             dfr.done = True       # this consumer walks the chunks itself
@@ -675,6 +688,7 @@ class Conv2dFn(torch.autograd.Function):
                            stats[1][g_].data_ptr(), 1)
                 else:
                     L.call("bg_conv2d_fwd", dc, xp, arena.weight_ptr(wslot), None, yp)
+            dfr.finish()
             if weight.requires_grad:
                 ctx.save_for_backward(x)
             ctx.meta = (arena, wslot, bslot, stride, pad, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
@@ -727,9 +741,16 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         arena, wslot, bslot, stride, pad, dil, ho, wo, xshape, xdtype, xdev = ctx.meta
-        g = nhwc(g)
         n, h, w, cin = xshape
         kp, kh, kw, cp = wslot.phys_shape
+        up = take_deferred(g) if _CHUNK_BWD else None     # a pending producer of g (the BatchNorm backward's apply pass)
+        if up is not None and (bslot is not None or getattr(arena, "fp8", False) or splitk_plan(n * h * w, cin, kp, kh, kw, xdtype)
+                               or not _is_nhwc(g, 8 if g.dtype == torch.bfloat16 else 4) or g.shape[3] != kp):
+            up.run_all()
+            up = None
+        if up is not None:
+            return Conv2dFn._backward_chunked(ctx, g, up)
+        g = nhwc(g)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(n, h, w, cin, xdtype, xdev)
@@ -773,6 +794,56 @@ class Conv2dFn(torch.autograd.Function):
                 wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)
             else:
                 wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
+        return dx, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_chunked(ctx, g, up):
+        """backward() behind a pending producer of g, chunk by chunk: producer(chunk), this layer's data gradient(chunk) and --
+        for layers whose weight gradient is a per-layer launch -- its weight gradient(chunk), each reading the chunk of g out of
+        the Infinity Cache.  With an input gradient wanted the chain is handed on as a Deferred note on dx (the depthwise
+        backward that reads dx walks it); weight gradients that need all of g (grouped / gang launches) wait in `after`."""
+        arena, wslot, bslot, stride, pad, dil, ho, wo, xshape, xdtype, xdev = ctx.meta
+        n, h, w, cin = xshape
+        kp, kh, kw, cp = wslot.phys_shape
+        dt, es = L.dt(xdtype), g.element_size()
+        need_dx, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = new_act(n, h, w, cin, xdtype, xdev) if need_dx else None
+        ldg, lddx = ld_of(g), 0 if dx is None else ld_of(dx)
+        dxp = None if dx is None else dx.data_ptr()
+        after, w_chunk = [], None
+        if need_w:
+            (x,) = ctx.saved_tensors
+            arena.ensure_grad(wslot)
+            ldx = ld_of(x)
+            desc = L.ConvDesc(dt, n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ldx, ldg)
+            if (wgrad_group_ok(xdtype, kh, kw, stride, pad, dil, False) and x.shape[3] == cin and _gang_shape_ok(cin, kp)
+                    and n * h * w * max(ldx, ldg) * 2 < (1 << 31)):
+                wgrad_group_add(xdev, x, g, arena.grad_ptr(wslot), n * h * w, cin, kp, desc)   # queued: launched when the pass ends
+            elif wgrad_taps_ok(xdtype, n, h, w, cin, kp, kh, kw, stride, pad, dil, False, ldx, ldg):
+                def taps(x=x, g=g):
+                    tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), 0]], dtype=torch.int64)
+                    wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)
+                after.append(taps)
+            else:
+                def w_chunk(n0, n1, x=x, g=g):
+                    dc = L.ConvDesc(dt, n1 - n0, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ldx, ldg)
+                    wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", dc, x.data_ptr() + n0 * h * w * ldx * es,
+                               g.data_ptr() + n0 * ho * wo * ldg * es, arena.grad_ptr(wslot), None)
+
+        def run(n0, n1, g=g):
+            if need_dx:
+                dc = L.ConvDesc(dt, n1 - n0, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, lddx, ldg)
+                L.call("bg_conv2d_bwd_data", dc, g.data_ptr() + n0 * ho * wo * ldg * es, arena.weight_t_ptr(wslot),
+                       dxp + n0 * h * w * lddx * es)
+            if w_chunk is not None:
+                w_chunk(n0, n1)
+
+        d = chain_deferred(up, run, n, up.groups, up.chunk, f"dgrad {n}x{h}x{w}x{cin}<-{kp}")
+        d.after.extend(after)
+        if need_dx:
+            defer_on(dx, d)
+        else:
+            d.run_all()
         return dx, None, None, None, None, None, None, None, None, None
 
 
@@ -855,8 +926,7 @@ def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups, 
         groups = 1
     ch = chunk_images(n, groups, ho * wo * ldy * es) if _is_nhwc(y, 8 if x.dtype == torch.bfloat16 else 4) else 0
     if up is not None and not ch:      # the input's producer is pending but this output is not chunk-worthy: produce the input now
-        up.done = True
-        up.run(0, up.n)
+        up.run_all()
         up = None
 
     yp = y.data_ptr()      # (the note hangs on y: the closure must not hold y itself -- a reference cycle would keep 450 MB alive)
@@ -866,7 +936,7 @@ def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups, 
         L.call("bg_dwconv3x3_fwd", d, x.data_ptr() + n0 * h * w * ldx * es, wptr, yp + n0 * ho * wo * ldy * es)
 
     if ch:
-        defer_on(y, chain_deferred(up, run, n, groups, ch))
+        defer_on(y, chain_deferred(up, run, n, groups, ch, f"dw {n}x{ho}x{wo}x{c} s{stride}"))
     else:
         run(0, n)
 
@@ -875,8 +945,7 @@ def _take_upstream(x):
     """The pending producer of x if x can be addressed as it stands (else it is produced now by nhwc())."""
     up = take_deferred(x)
     if up is not None and not _is_nhwc(x, 8 if x.dtype == torch.bfloat16 else 4):
-        up.done = True
-        up.run(0, up.n)
+        up.run_all()
         up = None
     return up
 
@@ -949,12 +1018,17 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
         arena, wslot, dil, xshape, xdtype, xdev = ctx.meta
         n, h, w, c = xshape
         dt = L.dt(xdtype)
+        tail = ctx.tail
+        use_fork = tail is not None and tail.claimed == 1 and ctx.needs_input_grad[0] and g is not None and gskip is not None
+        up = take_deferred(g) if (g is not None and _CHUNK_BWD) else None    # a pending chain producing g (before nhwc() runs it whole)
+        if up is not None and not (use_fork and _is_nhwc(g, 8)):
+            up.run_all()
+            up = None
         if g is not None:
             g = nhwc(g)
         if gskip is not None:
             gskip = nhwc(gskip)
         dx = None
-        tail = ctx.tail
         if tail is not None and tail.claimed == 1 and ctx.needs_input_grad[0] and g is not None and gskip is not None:
             # ONE pass: depthwise data gradient + skip gradient, the producer's activation derivative, the depthwise weight
             # gradient and the producer's two BatchNorm-backward sums (bg_dwconv3x3_bwd_fork); the producer's backward finds
@@ -965,11 +1039,25 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
                 arena.ensure_grad(wslot)
             gout = new_act(n, h, w, c, xdtype, xdev)
             sums = _f64(2, tail.groups, c, device=xdev)
-            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-            L.call("bg_dwconv3x3_bwd_fork", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), gskip.data_ptr(),
-                   ld_of(gskip), tail.x.data_ptr(), ld_of(tail.x), tail.mean.data_ptr(), tail.rstd.data_ptr(), tail.groups,
-                   tail.act, gout.data_ptr(), ld_of(gout), arena.grad_ptr(wslot) if want_dw else None, sums[0].data_ptr(),
-                   sums[1].data_ptr())
+            dwp = arena.grad_ptr(wslot) if want_dw else None
+            if up is None:
+                desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+                L.call("bg_dwconv3x3_bwd_fork", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), gskip.data_ptr(),
+                       ld_of(gskip), tail.x.data_ptr(), ld_of(tail.x), tail.mean.data_ptr(), tail.rstd.data_ptr(), tail.groups,
+                       tail.act, gout.data_ptr(), ld_of(gout), dwp, sums[0].data_ptr(), sums[1].data_ptr())
+            else:       # behind a pending chain producing g: chunk by chunk (see Conv2dFn._backward_chunked)
+                es, hw, ipg = x.element_size(), h * w, n // tail.groups
+                for n0 in range(0, n, up.chunk):
+                    n1 = min(n, n0 + up.chunk)
+                    up.run(n0, n1)
+                    g_, o = n0 // ipg, n0 * hw * es
+                    dc = L.DwDesc(dt, n1 - n0, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+                    L.call("bg_dwconv3x3_bwd_fork", dc, g.data_ptr() + o * ld_of(g), arena.weight_ptr(wslot), x.data_ptr() + o * ld_of(x),
+                           gskip.data_ptr() + o * ld_of(gskip), ld_of(gskip), tail.x.data_ptr() + o * ld_of(tail.x), ld_of(tail.x),
+                           tail.mean[g_].data_ptr(), tail.rstd[g_].data_ptr(), 1, tail.act, gout.data_ptr() + o * ld_of(gout),
+                           ld_of(gout), dwp, sums[0][g_].data_ptr(), sums[1][g_].data_ptr())
+                up.done = True
+                up.finish()
             tail.sums, tail.gout = sums, gout
             return gout, None, None, None, None, None
         if ctx.needs_input_grad[0]:
@@ -1064,6 +1152,47 @@ def current_bn_repeat() -> int:
 
 
 
+def _apply_bwd(dt, g, y, x, s, gptr, bptr, mean, rstd, dg, db, dx, dres, n, h, w, c, groups, act, q_site=None):
+    """The second pass of the BatchNorm backward (bg_norm_act_bwd_apply_stats: dx, optionally the residual gradient, dgamma /
+    dbeta) -- at once, or, for gradients too large to survive in the Infinity Cache until the data-gradient GEMM reads them,
+    as a Deferred note on dx that the reader runs chunk by chunk (the sums `s` are complete here: whoever produced them saw
+    the whole tensor).  y: the stored output for the activation's branch, or None."""
+    rows = n * h * w
+    es = x.element_size()
+    vec_ = 8 if x.dtype == torch.bfloat16 else 4
+    ch = 0
+    if (_CHUNK_BWD and dx is not None and q_site is None and _is_nhwc(g, vec_) and _is_nhwc(x, vec_) and _is_nhwc(dx, vec_)
+            and (y is None or _is_nhwc(y, vec_)) and (dres is None or _is_nhwc(dres, vec_))
+            and torch._C._current_graph_task_id() >= 0):
+        ch = chunk_images(n, groups, h * w * ld_of(dx) * es)
+    if not ch:
+        args = (dt, g.data_ptr(), ld_of(g), L.ptr(y), 0 if y is None else ld_of(y), x.data_ptr(), ld_of(x), s[0].data_ptr(),
+                s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx),
+                L.ptr(dres), 0 if dres is None else ld_of(dres), rows, c, groups, act)
+        _apply_stats_maybe_q8(q_site, dx, args, n, h, w, c)
+        return
+    if dg is not None:       # parameter gradients once per tensor (the chunk launches carry none)
+        tab = _e32(3, groups, c, device=x.device)
+        L.call("bg_norm_bwd_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, mean.data_ptr(),
+               rstd.data_ptr(), 1, tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr(), dg, db)
+    hw, ipg = h * w, n // groups
+    ldg, ldy_, ldx, lddx, lddr = ld_of(g), 0 if y is None else ld_of(y), ld_of(x), ld_of(dx), 0 if dres is None else ld_of(dres)
+    dxp, drp = dx.data_ptr(), None if dres is None else dres.data_ptr()
+
+    def run(n0, n1, g=g, y=y, x=x):      # (holds its inputs; not dx / dres, on which the note hangs)
+        g_, o = n0 // ipg, n0 * hw * es
+        L.call("bg_norm_act_bwd_apply_stats_part", dt, g.data_ptr() + o * ldg, ldg, None if y is None else y.data_ptr() + o * ldy_, ldy_,
+               x.data_ptr() + o * ldx, ldx, s[0][g_].data_ptr(), s[1][g_].data_ptr(), gptr, bptr, mean[g_].data_ptr(),
+               rstd[g_].data_ptr(), 1, dxp + o * lddx, lddx, None if drp is None else drp + o * lddr, lddr, (n1 - n0) * hw, c, act,
+               rows // groups)
+
+    d = Deferred(run, n, groups, ch, f"bn-apply-bwd {n}x{h}x{w}x{c}")
+    defer_on(dx, d)
+    if dres is not None:     # the residual gradient is written by the same launches: its reader must trigger them as well
+        _DEFERRED[dres.data_ptr()] = (__import__("weakref").ref(dres), d)
+        dres._bg_defer = d
+
+
 class NormActFn(torch.autograd.Function):
     """y = act( norm(x) + res ).
 
@@ -1120,7 +1249,7 @@ class NormActFn(torch.autograd.Function):
                            None if res is None else res.data_ptr() + n0 * hw * ldr * es, ldr, yp + n0 * hw * ldy * es, ldy,
                            (n1 - n0) * hw, c, 1, int(act))
 
-                defer_on(y, Deferred(run, n, groups, ch))
+                defer_on(y, Deferred(run, n, groups, ch, f"bn-act {n}x{h}x{w}x{c}"))
             else:
                 # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
                 L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
@@ -1169,9 +1298,8 @@ class NormActFn(torch.autograd.Function):
                     arena.ensure_grad(gslot)
                     arena.ensure_grad(bslot)
                     dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
-                L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), None, 0, x.data_ptr(), ld_of(x),
-                       s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot), arena.master_ptr(bslot), mean.data_ptr(),
-                       rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), None, 0, rows, c, groups, 0)
+                _apply_bwd(dt, g, None, x, s, arena.master_ptr(gslot), arena.master_ptr(bslot), mean, rstd, dg, db, dx, None,
+                           n, h, w, c, groups, 0)
             return (dx, g if need_res else None) + (None,) * 16
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
@@ -1199,11 +1327,15 @@ class NormActFn(torch.autograd.Function):
                 arena.ensure_grad(bslot)
                 dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
             # finalize (coefficients, dgamma/dbeta) is folded into the apply kernel
-            args = (dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
-                    s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
-                    1 if batch_stats else 0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
-                    0 if dres is None else ld_of(dres), rows, c, groups, act)
-            _apply_stats_maybe_q8(ctx.q_site if (batch_stats and act) else None, dx, args, *x.shape)
+            if batch_stats:
+                _apply_bwd(dt, g, None if yptr is None else y, x, s, gptr, bptr, mean, rstd, dg, db, dx, dres, n, h, w, c, groups,
+                           act, ctx.q_site if act else None)
+            else:
+                args = (dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
+                        s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
+                        0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
+                        0 if dres is None else ld_of(dres), rows, c, groups, act)
+                _apply_stats_maybe_q8(None, dx, args, *x.shape)
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
@@ -1259,7 +1391,7 @@ class NormActDwConvFn(torch.autograd.Function):
                 L.call("bg_dwconv3x3_fwd_pre", d_, x.data_ptr() + n0 * h * w * ldx * es, scale[g_].data_ptr(), shift[g_].data_ptr(), 1,
                        int(act), wptr, yp + n0 * h * w * ldy * es)
 
-            defer_on(y, Deferred(run, n, groups, ch))
+            defer_on(y, Deferred(run, n, groups, ch, f"bn-act-dw {n}x{h}x{w}x{c}"))
         elif _FOLD_FINALIZE and c <= 4096:
             # the depthwise kernel finalises the statistics itself (no launch between the GEMM and it)
             L.call("bg_dwconv3x3_fwd_pre_stats", desc, x.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot),
@@ -1280,6 +1412,10 @@ class NormActDwConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, mean, rstd, scale, shift = ctx.saved_tensors
         arena, gslot, bslot, wslot, act, groups, dil = ctx.meta
+        up = take_deferred(g) if _CHUNK_BWD else None    # a pending chain (BatchNorm apply -> pointwise data gradient) producing g
+        if up is not None and not _is_nhwc(g, 8 if g.dtype == torch.bfloat16 else 4):
+            up.run_all()
+            up = None
         g = nhwc(g)
         n, h, w, c = x.shape
         dev, dt = x.device, L.dt(x.dtype)
@@ -1292,6 +1428,9 @@ class NormActDwConvFn(torch.autograd.Function):
         fused = (_DW_FUSED_BWD and x.dtype == torch.bfloat16 and (need_dx or want_affine_grads)
                  and h * w * max(ld_of(x), ld_of(g)) * 2 < (1 << 31)
                  and (ctx.needs_input_grad[3] or (dil == 1 and rows * c >= 150_000_000)))
+        if up is not None and not fused:
+            up.run_all()
+            up = None
         if ctx.needs_input_grad[3]:
             arena.ensure_grad(wslot)
             if not fused:
@@ -1306,10 +1445,25 @@ class NormActDwConvFn(torch.autograd.Function):
         if fused:
             # ONE pass over g and x: the depthwise data gradient, the depthwise weight gradient on the recomputed activation
             # and the two statistics of the BatchNorm backward (three launches and six tensor passes in round 2)
-            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-            L.call("bg_dwconv3x3_bwd_fused", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), scale.data_ptr(),
-                   shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), groups, act, da.data_ptr(), ld_of(da),
-                   arena.grad_ptr(wslot) if ctx.needs_input_grad[3] else None, s[0].data_ptr(), s[1].data_ptr())
+            dwp = arena.grad_ptr(wslot) if ctx.needs_input_grad[3] else None
+            if up is None:
+                desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+                L.call("bg_dwconv3x3_bwd_fused", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), scale.data_ptr(),
+                       shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), groups, act, da.data_ptr(), ld_of(da), dwp,
+                       s[0].data_ptr(), s[1].data_ptr())
+            else:
+                # the chain's chunk, then this unit's one-pass backward on it: the chunk of g comes out of the Infinity Cache
+                es, hw, ipg = x.element_size(), h * w, n // groups
+                for n0 in range(0, n, up.chunk):
+                    n1 = min(n, n0 + up.chunk)
+                    up.run(n0, n1)
+                    g_, o = n0 // ipg, n0 * hw * es
+                    dc = L.DwDesc(dt, n1 - n0, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+                    L.call("bg_dwconv3x3_bwd_fused", dc, g.data_ptr() + o * ld_of(g), arena.weight_ptr(wslot), x.data_ptr() + o * ld_of(x),
+                           scale[g_].data_ptr(), shift[g_].data_ptr(), mean[g_].data_ptr(), rstd[g_].data_ptr(), 1, act,
+                           da.data_ptr() + o * ld_of(da), ld_of(da), dwp, s[0][g_].data_ptr(), s[1][g_].data_ptr())
+                up.done = True
+                up.finish()
         else:
             desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(da), ld_of(g))
             L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), da.data_ptr())
@@ -1321,10 +1475,7 @@ class NormActDwConvFn(torch.autograd.Function):
             arena.ensure_grad(bslot)
             dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
-        args = (dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x),
-                s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx),
-                0 if dx is None else ld_of(dx), None, 0, rows, c, groups, act)
-        _apply_stats_maybe_q8(ctx.q_site if act else None, dx, args, n, h, w, c)
+        _apply_bwd(dt, da, None, x, s, gptr, bptr, mean, rstd, dg, db, dx, None, n, h, w, c, groups, act, ctx.q_site if act else None)
         return (dx,) + (None,) * 15
 
 

@@ -203,7 +203,7 @@ def test_image_chunked_schedule_is_the_same_arithmetic(monkeypatch, dtype):
         monkeypatch.setattr(ops.Deferred, "__init__", orig)
     a, b = out[False], out[True]
     assert a[4] == 0 and b[4] >= 40, f"the chunked schedule engaged on {b[4]} producers"
-    assert not ops._DEFERRED, "every note was consumed"
+    assert not ops._DEFERRED, f"notes nobody consumed: {[(d.tag, d.done, r() is None) for r, d in ops._DEFERRED.values()]}"
     # identical kernels on sub-batches.  What may differ is the grouping of the BatchNorm statistic partial sums: a
     # convolution tile of 128 pixels spans several images of the small maps here (16 pixels per image at the bottom), so the
     # fp32 per-tile sums are other sets of terms (1e-7 relative); where every image is whole tiles (the product's case: the
