@@ -79,8 +79,10 @@ class Deferred:
             f()
 
     def run_all(self):
+        """The whole producer, still chunk by chunk: a run() call must stay inside one statistic group."""
         self.done = True
-        self.run(0, self.n)
+        for n0 in range(0, self.n, self.chunk):
+            self.run(n0, min(self.n, n0 + self.chunk))
         self.finish()
 
 
@@ -387,6 +389,7 @@ class GradMilestoneFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        flush_deferred(g)
         ddp = getattr(ctx.arena, "ddp", None)
         if ddp is not None:
             ddp.ms_pending -= 1
@@ -1569,6 +1572,7 @@ class GlobalAvgPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         n, nd, h, w, c, dtype = ctx.meta
+        flush_deferred(g)
         g = g.contiguous()
         gf = _f32(n, c, device=g.device)
         L.call("bg_cast_rows", L.dt(g.dtype), L.F32, g.data_ptr(), c, gf.data_ptr(), c, n, c)
@@ -1598,6 +1602,7 @@ class ConcatFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        flush_deferred(g)
         outs, off = [], 0
         for c in ctx.cs:
             outs.append(g[..., off:off + c])  # zero-copy channel slices; consumers honour the pixel stride
