@@ -88,8 +88,6 @@ _SIGS = {
                               c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
     "bg_norm_act_bwd_apply_stats": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                     c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp],
-    "bg_norm_act_bwd_apply_stats_part": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
-                                         c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp],
     "bg_norm_act_bwd_apply_stats_q8": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                     c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
     "bg_norm_act_bwd_reduce": [c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
@@ -274,8 +272,6 @@ def _alg_bytes(name, a) -> float:
         return float(a[14]) * a[15] * _es(a[0]) * nn(1, 3, 5, 10, 12)
     if name == "bg_norm_act_bwd_apply_stats_q8":     # + one byte per element for the e5m2 copy
         return float(a[20]) * a[21] * (_es(a[0]) * nn(1, 3, 5, 16, 18) + 1)
-    if name == "bg_norm_act_bwd_apply_stats_part":
-        return float(a[18]) * a[19] * _es(a[0]) * nn(1, 3, 5, 14, 16)
     if name == "bg_norm_act_bwd_apply_stats":
         return float(a[20]) * a[21] * _es(a[0]) * nn(1, 3, 5, 16, 18)
     if name == "bg_nchw_to_nhwc":

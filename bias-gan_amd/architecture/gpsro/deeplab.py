@@ -380,7 +380,9 @@ class Xception(BGModule):
 
     def forward_nhwc(self, x, want_low=True):
         x = conv_norm(self, self.conv1, self.bn1, x, act=True)
-        x = conv_norm(self, self.conv2, self.bn2, x, act=True)
+        # (block1 is the only reader of bn2's output and starts with its fork: it may take over the first half of bn2's
+        # backward -- ops.NormTail, bg_dwconv3x3_bwd_fork -- on the step's largest tensors, 450 - 900 MB at 1152 x 768)
+        x = conv_norm(self, self.conv2, self.bn2, x, act=True, offer_tail=True)
         # every block output below already carries the next block's leading LeakyReLU
         x = self.block1(x, activate_output=True)
         low = None

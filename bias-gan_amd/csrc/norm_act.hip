@@ -579,7 +579,6 @@ struct EwBwdParams {
     float* dgamma; float* dbeta;
     int train; int groups;
     int gx, gy;
-    long long stat_rows;   // rows per group the sums s1 / s2 were taken over, when the launch covers only a part of the group (0: rows_per_group)
     // Q8 (fp8 operand path): dx is ALSO written as e5m2 bytes -- the data-gradient GEMM of the pointwise convolution that
     // produced x reads it as its operand -- q = e5m2(clamp(dx_as_stored * 2^(*q_exp))), C rounded up to 16 with zero lanes,
     // and *q_amax = max(*q_amax, max |dx|) for the next step's exponent (bg_quant_fp8's contract, one pass saved)
@@ -610,7 +609,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
     extern __shared__ float ew_tab[];
     const int row_w = P.tx * VEC, nthr = P.tx * ty;
     {
-        const float inv_n = 1.f / (float)(P.stat_rows ? P.stat_rows : P.rows_per_group);
+        const float inv_n = 1.f / (float)P.rows_per_group;
         for (int ch = threadIdx.x; ch < row_w; ch += nthr) {
             const int cg = bx * row_w + ch;
             float a = 1.f, b = 0.f, cc0 = 0.f, s = 1.f, h = 0.f;
@@ -1022,7 +1021,7 @@ int bwd_apply_stats_impl(int32_t dtype, const void* dy, int32_t lddy, const void
                          const double* s1, const double* s2, const float* gamma, const float* beta, const float* mean,
                          const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
                          int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act, void* dxq, int32_t lddxq,
-                         const int32_t* q_exp, uint32_t* q_amax, void* stream, int64_t stat_rows = 0);
+                         const int32_t* q_exp, uint32_t* q_amax, void* stream);
 }
 
 extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
@@ -1034,19 +1033,6 @@ extern "C" int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_
                                            void* stream) {
     return bwd_apply_stats_impl(dtype, dy, lddy, y, ldy, x, ldx, s1, s2, gamma, beta, mean, rstd, train, dgamma, dbeta, dx, lddx,
                                 dres, lddres, rows, C, groups, act, nullptr, 0, nullptr, nullptr, stream);
-}
-
-// The same launch over a PART of one statistic group's rows (an image chunk of the chunked schedule, ops.Deferred): the
-// coefficients come from sums over stat_rows_per_group rows (the whole group), the launch walks `rows` of them.  One group
-// per call (s1 / s2 / mean / rstd point at the group's row); dgamma / dbeta are the whole-tensor launch's business.
-extern "C" int bg_norm_act_bwd_apply_stats_part(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
-                                                const void* x, int32_t ldx, const double* s1, const double* s2,
-                                                const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                                int32_t train, void* dx, int32_t lddx, void* dres, int32_t lddres, int64_t rows,
-                                                int32_t C, int32_t act, int64_t stat_rows_per_group, void* stream) {
-    BG_CHECK_ARG(stat_rows_per_group >= rows && rows > 0, "bg_norm_act_bwd_apply_stats_part: the part cannot exceed its group");
-    return bwd_apply_stats_impl(dtype, dy, lddy, y, ldy, x, ldx, s1, s2, gamma, beta, mean, rstd, train, nullptr, nullptr, dx, lddx,
-                                dres, lddres, rows, C, 1, act, nullptr, 0, nullptr, nullptr, stream, stat_rows_per_group);
 }
 
 extern "C" int bg_norm_act_bwd_apply_stats_q8(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy,
@@ -1070,7 +1056,7 @@ int bwd_apply_stats_impl(int32_t dtype, const void* dy, int32_t lddy, const void
                          const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx,
                          int32_t lddx, void* dres,
                          int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act, void* dxq, int32_t lddxq,
-                         const int32_t* q_exp, uint32_t* q_amax, void* stream, int64_t stat_rows) {
+                         const int32_t* q_exp, uint32_t* q_amax, void* stream) {
     int rc = check_rows(dtype, rows, C, groups, "bg_norm_act_bwd_apply_stats");
     if (rc) return rc;
     CHECK_LD(lddy, "bg_norm_act_bwd_apply_stats");
@@ -1098,7 +1084,6 @@ int bwd_apply_stats_impl(int32_t dtype, const void* dy, int32_t lddy, const void
                   t.rows_per_block, act, t.tx, t.ty, s1, s2, gamma, beta, mean, rstd, dgamma, dbeta, train, groups};
     P.gx = t.gx; P.gy = t.gy;
     P.dxq = (unsigned char*)dxq; P.lddxq = lddxq; P.q_exp = q_exp; P.q_amax = q_amax;
-    P.stat_rows = stat_rows;
     launch_bwd_apply(dtype, P, t, groups, (hipStream_t)stream);
     BG_CHECK_LAUNCH("norm_act_bwd_apply_kernel(stats)");
     return BG_OK;

@@ -51,96 +51,8 @@ def _is_nhwc(t: torch.Tensor, vec: int) -> bool:
     return True
 
 
-# ---------------------------------------------------------------- image-chunked producer -> consumer pairs
-# The entry flow's and the decoder's activations are 450 - 900 MB at 1152 x 768, batch 8: a tensor one kernel writes has left
-# the 256 MB Infinity Cache long before the next kernel reads it, and every such hand-over is a full HBM read (these layers
-# are HBM-bound: half of the step's time sits in launches of >= 400 MB).  Where a producer's ONLY reader is the next launch
-# and nothing batch-global lies between them (no BatchNorm statistics), the pair is run image chunk by image chunk --
-# producer(chunk), consumer(chunk) -- so that the consumer finds the chunk in the cache: the producer does not launch, it
-# leaves a Deferred note on its (allocated, still empty) output; a consumer that knows the protocol (Conv2dFn) walks the
-# chunks; every other consumer runs the whole producer first (nhwc() does that: every Function passes its inputs through it).
-# Same kernels, same arithmetic, per-image launches: results are bit-identical up to the order of statistic atomics.
-_CHUNK_MB = int(_os.environ.get("BGAMD_CHUNK_MB", "96"))     # target chunk size; 0 switches the chunked schedule off
-_CHUNK_BWD = _os.environ.get("BGAMD_CHUNK_BWD", "1") != "0"   # ... its backward chains (apply -> data gradient -> depthwise backward)
-
-
-class Deferred:
-    """run(n0, n1) launches the producer for images [n0, n1) of the tensor the note hangs on; `after` are launches that
-    need the WHOLE tensor (a grouped / per-layer weight gradient of a convolution in the chain) and run once the last
-    chunk is out: finish()."""
-    __slots__ = ("run", "n", "groups", "chunk", "done", "after", "tag")
-
-    def __init__(self, run, n, groups, chunk, tag=""):
-        self.run, self.n, self.groups, self.chunk, self.done, self.after, self.tag = run, n, groups, chunk, False, [], tag
-
-    def finish(self):
-        todo, self.after = self.after, []
-        for f in todo:
-            f()
-
-    def run_all(self):
-        """The whole producer, still chunk by chunk: a run() call must stay inside one statistic group."""
-        self.done = True
-        for n0 in range(0, self.n, self.chunk):
-            self.run(n0, min(self.n, n0 + self.chunk))
-        self.finish()
-
-
-def chunk_images(n: int, groups: int, bytes_per_image: int) -> int:
-    """Images per chunk for an intermediate tensor of n images, or 0 when the tensor is small enough to survive in the cache
-    whole (or the schedule is off).  A chunk never straddles two statistic groups."""
-    if _CHUNK_MB <= 0 or n * bytes_per_image <= 2 * _CHUNK_MB * (1 << 20):
-        return 0
-    per_group = n // max(groups, 1)
-    c = max(1, min(per_group, (_CHUNK_MB << 20) // max(bytes_per_image, 1)))
-    while per_group % c:
-        c -= 1
-    return c if c < n else 0
-
-
-_DEFERRED = {}     # data_ptr -> (weakref of the tensor the note was made for, Deferred): finds the note through a view as well
-
-
-def chain_deferred(up, run, n, groups, chunk, tag=""):
-    """A Deferred for `run`, behind the pending producer `up` of its input (None: none): the chain runs chunk by chunk,
-    upstream first.  The chunk size is the upstream's (one schedule per chain)."""
-    if up is None:
-        return Deferred(run, n, groups, chunk, tag)
-    up.done = True
-    urun = up.run
-    d = Deferred(lambda n0, n1: (urun(n0, n1), run(n0, n1))[1], n, groups, up.chunk, up.tag + " > " + tag)
-    d.after, up.after = up.after, []
-    return d
-
-
-def defer_on(y: torch.Tensor, d: Deferred):
-    import weakref
-    y._bg_defer = d
-    _DEFERRED[y.data_ptr()] = (weakref.ref(y), d)
-
-
-def take_deferred(t: torch.Tensor):
-    """The pending Deferred of `t` (by attribute, or by address for a view of the tensor it was made for), removed from the
-    registry; None if there is none."""
-    d = getattr(t, "_bg_defer", None)
-    if d is not None:
-        t._bg_defer = None
-    if _DEFERRED:
-        ent = _DEFERRED.pop(t.data_ptr(), None)
-        if ent is not None and d is None and ent[0]() is not None:     # (a dead weakref: the tensor died unread, the address was reused)
-            d = ent[1]
-    return d if d is not None and not d.done else None
-
-
-def flush_deferred(t: torch.Tensor):
-    d = take_deferred(t)
-    if d is not None:
-        d.run_all()
-
-
 def nhwc(t: torch.Tensor) -> torch.Tensor:
     """Return `t` if the kernels can address it as NHWC rows, else a packed copy."""
-    flush_deferred(t)
     vec = 8 if t.dtype == torch.bfloat16 else 4
     if _is_nhwc(t, vec):
         return t
@@ -381,7 +293,6 @@ class GradMilestoneFn(torch.autograd.Function):
         # freezes the critic around its autograd.grad) grad_milestone() inserts no node, and needs_input_grad[1] is False
         # for a node created while the probe did not require a gradient
         ctx.arena, ctx.off = arena, off
-        flush_deferred(x)
         # a network may be called more than once before one backward pass (D(real) and D(fake)): the tail is final when the
         # LAST of these nodes has run, so they are counted (reset by FlatAllReduce.finish())
         arena.ddp.ms_pending += 1
@@ -389,7 +300,6 @@ class GradMilestoneFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        flush_deferred(g)
         ddp = getattr(ctx.arena, "ddp", None)
         if ddp is not None:
             ddp.ms_pending -= 1
@@ -660,15 +570,7 @@ class Conv2dFn(torch.autograd.Function):
                 stats=None):
         """stats: optional zeroed fp64 [2, Cout_phys]; the kernel adds sum(y), sum(y^2) of the stored
         outputs to it from its accumulators (the batch statistics of the BatchNorm that follows)."""
-        dfr = take_deferred(x)
-        if dfr is not None and (bslot is not None or getattr(arena, "fp8", False)
-                                or not _is_nhwc(x, 8 if x.dtype == torch.bfloat16 else 4)):
-            dfr.run_all()         # a consumer the chunked schedule does not cover: the whole producer now
-            dfr = None
-        if dfr is not None:
-            dfr.done = True       # this consumer walks the chunks itself
-        else:
-            x = nhwc(x)
+        x = nhwc(x)
         n, h, w, cin = x.shape
         kp, kh, kw, cp = wslot.phys_shape
         assert cin == cp, f"conv expects {cp} input channels (padded), got {cin}"
@@ -676,26 +578,6 @@ class Conv2dFn(torch.autograd.Function):
         wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         y = new_act(n, ho, wo, kp, x.dtype, x.device)
         desc = L.ConvDesc(L.dt(x.dtype), n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
-        if dfr is not None:
-            # producer(chunk), this convolution(chunk): the chunk is read out of the Infinity Cache instead of HBM
-            es = x.element_size()
-            sgroups = 1 if stats is None else stats.shape[1]
-            for n0 in range(0, n, dfr.chunk):
-                n1 = min(n, n0 + dfr.chunk)
-                dfr.run(n0, n1)
-                dc = L.ConvDesc(L.dt(x.dtype), n1 - n0, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ld_of(x), ld_of(y))
-                xp, yp = x.data_ptr() + n0 * h * w * ld_of(x) * es, y.data_ptr() + n0 * ho * wo * ld_of(y) * es
-                if stats is not None:
-                    g_ = n0 // (n // sgroups)             # a chunk lies inside one statistic group (chunk_images)
-                    L.call("bg_conv2d_fwd_stats", dc, xp, arena.weight_ptr(wslot), yp, stats[0][g_].data_ptr(),
-                           stats[1][g_].data_ptr(), 1)
-                else:
-                    L.call("bg_conv2d_fwd", dc, xp, arena.weight_ptr(wslot), None, yp)
-            dfr.finish()
-            if weight.requires_grad:
-                ctx.save_for_backward(x)
-            ctx.meta = (arena, wslot, bslot, stride, pad, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
-            return y
         splits = splitk_plan(n * ho * wo, kp, cin, kh, kw, x.dtype) if bslot is None else 0
         xq = fp8_copy_of(x)
         use8 = x.dtype == torch.bfloat16 and not splits and fp8_layer_ok(arena, wslot, kh, kw, prequantised=xq is not None)
@@ -744,16 +626,9 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         arena, wslot, bslot, stride, pad, dil, ho, wo, xshape, xdtype, xdev = ctx.meta
+        g = nhwc(g)
         n, h, w, cin = xshape
         kp, kh, kw, cp = wslot.phys_shape
-        up = take_deferred(g) if _CHUNK_BWD else None     # a pending producer of g (the BatchNorm backward's apply pass)
-        if up is not None and (bslot is not None or getattr(arena, "fp8", False) or splitk_plan(n * h * w, cin, kp, kh, kw, xdtype)
-                               or not _is_nhwc(g, 8 if g.dtype == torch.bfloat16 else 4) or g.shape[3] != kp):
-            up.run_all()
-            up = None
-        if up is not None:
-            return Conv2dFn._backward_chunked(ctx, g, up)
-        g = nhwc(g)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new_act(n, h, w, cin, xdtype, xdev)
@@ -797,56 +672,6 @@ class Conv2dFn(torch.autograd.Function):
                 wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)
             else:
                 wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
-        return dx, None, None, None, None, None, None, None, None, None
-
-    @staticmethod
-    def _backward_chunked(ctx, g, up):
-        """backward() behind a pending producer of g, chunk by chunk: producer(chunk), this layer's data gradient(chunk) and --
-        for layers whose weight gradient is a per-layer launch -- its weight gradient(chunk), each reading the chunk of g out of
-        the Infinity Cache.  With an input gradient wanted the chain is handed on as a Deferred note on dx (the depthwise
-        backward that reads dx walks it); weight gradients that need all of g (grouped / gang launches) wait in `after`."""
-        arena, wslot, bslot, stride, pad, dil, ho, wo, xshape, xdtype, xdev = ctx.meta
-        n, h, w, cin = xshape
-        kp, kh, kw, cp = wslot.phys_shape
-        dt, es = L.dt(xdtype), g.element_size()
-        need_dx, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dx = new_act(n, h, w, cin, xdtype, xdev) if need_dx else None
-        ldg, lddx = ld_of(g), 0 if dx is None else ld_of(dx)
-        dxp = None if dx is None else dx.data_ptr()
-        after, w_chunk = [], None
-        if need_w:
-            (x,) = ctx.saved_tensors
-            arena.ensure_grad(wslot)
-            ldx = ld_of(x)
-            desc = L.ConvDesc(dt, n, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ldx, ldg)
-            if (wgrad_group_ok(xdtype, kh, kw, stride, pad, dil, False) and x.shape[3] == cin and _gang_shape_ok(cin, kp)
-                    and n * h * w * max(ldx, ldg) * 2 < (1 << 31)):
-                wgrad_group_add(xdev, x, g, arena.grad_ptr(wslot), n * h * w, cin, kp, desc)   # queued: launched when the pass ends
-            elif wgrad_taps_ok(xdtype, n, h, w, cin, kp, kh, kw, stride, pad, dil, False, ldx, ldg):
-                def taps(x=x, g=g):
-                    tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), 0]], dtype=torch.int64)
-                    wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)
-                after.append(taps)
-            else:
-                def w_chunk(n0, n1, x=x, g=g):
-                    dc = L.ConvDesc(dt, n1 - n0, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, ldx, ldg)
-                    wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", dc, x.data_ptr() + n0 * h * w * ldx * es,
-                               g.data_ptr() + n0 * ho * wo * ldg * es, arena.grad_ptr(wslot), None)
-
-        def run(n0, n1, g=g):
-            if need_dx:
-                dc = L.ConvDesc(dt, n1 - n0, h, w, cin, ho, wo, kp, kh, kw, stride, pad, dil, lddx, ldg)
-                L.call("bg_conv2d_bwd_data", dc, g.data_ptr() + n0 * ho * wo * ldg * es, arena.weight_t_ptr(wslot),
-                       dxp + n0 * h * w * lddx * es)
-            if w_chunk is not None:
-                w_chunk(n0, n1)
-
-        d = chain_deferred(up, run, n, up.groups, up.chunk, f"dgrad {n}x{h}x{w}x{cin}<-{kp}")
-        d.after.extend(after)
-        if need_dx:
-            defer_on(dx, d)
-        else:
-            d.run_all()
         return dx, None, None, None, None, None, None, None, None, None
 
 
@@ -920,51 +745,18 @@ def avgpool2x2(x, p: int):
     return AvgPool2x2Fn.apply(x, int(p))
 
 
-def _dw_fwd_maybe_deferred(x, y, wptr, n, h, w, c, ho, wo, stride, dil, groups, up=None):
-    """bg_dwconv3x3_fwd now, or -- for a tensor too large to survive in the Infinity Cache -- as a Deferred note on y that
-    the pointwise convolution reading y runs chunk by chunk (see the chunked-schedule comment at the top of this file)."""
-    dt, es = L.dt(x.dtype), x.element_size()
-    ldx, ldy = ld_of(x), ld_of(y)
-    if n % max(groups, 1):
-        groups = 1
-    ch = chunk_images(n, groups, ho * wo * ldy * es) if _is_nhwc(y, 8 if x.dtype == torch.bfloat16 else 4) else 0
-    if up is not None and not ch:      # the input's producer is pending but this output is not chunk-worthy: produce the input now
-        up.run_all()
-        up = None
-
-    yp = y.data_ptr()      # (the note hangs on y: the closure must not hold y itself -- a reference cycle would keep 450 MB alive)
-
-    def run(n0, n1):
-        d = L.DwDesc(dt, n1 - n0, h, w, c, ho, wo, stride, dil, ldx, ldy)
-        L.call("bg_dwconv3x3_fwd", d, x.data_ptr() + n0 * h * w * ldx * es, wptr, yp + n0 * ho * wo * ldy * es)
-
-    if ch:
-        defer_on(y, chain_deferred(up, run, n, groups, ch, f"dw {n}x{ho}x{wo}x{c} s{stride}"))
-    else:
-        run(0, n)
-
-
-def _take_upstream(x):
-    """The pending producer of x if x can be addressed as it stands (else it is produced now by nhwc())."""
-    up = take_deferred(x)
-    if up is not None and not _is_nhwc(x, 8 if x.dtype == torch.bfloat16 else 4):
-        up.run_all()
-        up = None
-    return up
-
-
 class DwConv3x3Fn(torch.autograd.Function):
     """Depthwise 3x3 of SeparableConv2d_same with fixed_padding folded in (bg_dwconv3x3_*)."""
 
     @staticmethod
     def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, stride, dil):
-        up = _take_upstream(x)
         x = nhwc(x)
         n, h, w, c = x.shape
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         ho, wo = -(-h // stride), -(-w // stride)
         y = new_act(n, ho, wo, c, x.dtype, x.device)
-        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, ho, wo, stride, dil, current_bn_groups(), up)
+        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, ho, wo, stride, dil, ld_of(x), ld_of(y))
+        L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
         if weight.requires_grad:
             ctx.save_for_backward(x)
         ctx.meta = (arena, wslot, stride, dil, ho, wo, tuple(x.shape), x.dtype, x.device)
@@ -1000,12 +792,12 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, arena: Arena, wslot: ParamSlot, dil, tail=None):
         """tail: the ops.NormTail of the node that produced x (it offers the first half of its backward), or None."""
-        up = _take_upstream(x)
         x = nhwc(x)
         n, h, w, c = x.shape
         assert wslot.phys_shape == (3, 3, c), (wslot.phys_shape, c)
         y = new_act(n, h, w, c, x.dtype, x.device)
-        _dw_fwd_maybe_deferred(x, y, arena.weight_ptr(wslot), n, h, w, c, h, w, 1, dil, current_bn_groups(), up)
+        desc = L.DwDesc(L.dt(x.dtype), n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
+        L.call("bg_dwconv3x3_fwd", desc, x.data_ptr(), arena.weight_ptr(wslot), y.data_ptr())
         ctx.tail = None
         if (tail is not None and _FORK_FUSED and dil == 1 and x.dtype == torch.bfloat16 and ctx.needs_input_grad[0]
                 and tail.y_ptr == x.data_ptr() and h * w * max(ld_of(x), ld_of(y), ld_of(tail.x)) * 2 < (1 << 31)):
@@ -1021,17 +813,12 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
         arena, wslot, dil, xshape, xdtype, xdev = ctx.meta
         n, h, w, c = xshape
         dt = L.dt(xdtype)
-        tail = ctx.tail
-        use_fork = tail is not None and tail.claimed == 1 and ctx.needs_input_grad[0] and g is not None and gskip is not None
-        up = take_deferred(g) if (g is not None and _CHUNK_BWD) else None    # a pending chain producing g (before nhwc() runs it whole)
-        if up is not None and not (use_fork and _is_nhwc(g, 8)):
-            up.run_all()
-            up = None
         if g is not None:
             g = nhwc(g)
         if gskip is not None:
             gskip = nhwc(gskip)
         dx = None
+        tail = ctx.tail
         if tail is not None and tail.claimed == 1 and ctx.needs_input_grad[0] and g is not None and gskip is not None:
             # ONE pass: depthwise data gradient + skip gradient, the producer's activation derivative, the depthwise weight
             # gradient and the producer's two BatchNorm-backward sums (bg_dwconv3x3_bwd_fork); the producer's backward finds
@@ -1042,25 +829,11 @@ class ForkDwConv3x3Fn(torch.autograd.Function):
                 arena.ensure_grad(wslot)
             gout = new_act(n, h, w, c, xdtype, xdev)
             sums = _f64(2, tail.groups, c, device=xdev)
-            dwp = arena.grad_ptr(wslot) if want_dw else None
-            if up is None:
-                desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-                L.call("bg_dwconv3x3_bwd_fork", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), gskip.data_ptr(),
-                       ld_of(gskip), tail.x.data_ptr(), ld_of(tail.x), tail.mean.data_ptr(), tail.rstd.data_ptr(), tail.groups,
-                       tail.act, gout.data_ptr(), ld_of(gout), dwp, sums[0].data_ptr(), sums[1].data_ptr())
-            else:       # behind a pending chain producing g: chunk by chunk (see Conv2dFn._backward_chunked)
-                es, hw, ipg = x.element_size(), h * w, n // tail.groups
-                for n0 in range(0, n, up.chunk):
-                    n1 = min(n, n0 + up.chunk)
-                    up.run(n0, n1)
-                    g_, o = n0 // ipg, n0 * hw * es
-                    dc = L.DwDesc(dt, n1 - n0, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-                    L.call("bg_dwconv3x3_bwd_fork", dc, g.data_ptr() + o * ld_of(g), arena.weight_ptr(wslot), x.data_ptr() + o * ld_of(x),
-                           gskip.data_ptr() + o * ld_of(gskip), ld_of(gskip), tail.x.data_ptr() + o * ld_of(tail.x), ld_of(tail.x),
-                           tail.mean[g_].data_ptr(), tail.rstd[g_].data_ptr(), 1, tail.act, gout.data_ptr() + o * ld_of(gout),
-                           ld_of(gout), dwp, sums[0][g_].data_ptr(), sums[1][g_].data_ptr())
-                up.done = True
-                up.finish()
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+            L.call("bg_dwconv3x3_bwd_fork", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), gskip.data_ptr(),
+                   ld_of(gskip), tail.x.data_ptr(), ld_of(tail.x), tail.mean.data_ptr(), tail.rstd.data_ptr(), tail.groups,
+                   tail.act, gout.data_ptr(), ld_of(gout), arena.grad_ptr(wslot) if want_dw else None, sums[0].data_ptr(),
+                   sums[1].data_ptr())
             tail.sums, tail.gout = sums, gout
             return gout, None, None, None, None, None
         if ctx.needs_input_grad[0]:
@@ -1155,47 +928,6 @@ def current_bn_repeat() -> int:
 
 
 
-def _apply_bwd(dt, g, y, x, s, gptr, bptr, mean, rstd, dg, db, dx, dres, n, h, w, c, groups, act, q_site=None):
-    """The second pass of the BatchNorm backward (bg_norm_act_bwd_apply_stats: dx, optionally the residual gradient, dgamma /
-    dbeta) -- at once, or, for gradients too large to survive in the Infinity Cache until the data-gradient GEMM reads them,
-    as a Deferred note on dx that the reader runs chunk by chunk (the sums `s` are complete here: whoever produced them saw
-    the whole tensor).  y: the stored output for the activation's branch, or None."""
-    rows = n * h * w
-    es = x.element_size()
-    vec_ = 8 if x.dtype == torch.bfloat16 else 4
-    ch = 0
-    if (_CHUNK_BWD and dx is not None and q_site is None and _is_nhwc(g, vec_) and _is_nhwc(x, vec_) and _is_nhwc(dx, vec_)
-            and (y is None or _is_nhwc(y, vec_)) and (dres is None or _is_nhwc(dres, vec_))
-            and torch._C._current_graph_task_id() >= 0):
-        ch = chunk_images(n, groups, h * w * ld_of(dx) * es)
-    if not ch:
-        args = (dt, g.data_ptr(), ld_of(g), L.ptr(y), 0 if y is None else ld_of(y), x.data_ptr(), ld_of(x), s[0].data_ptr(),
-                s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx),
-                L.ptr(dres), 0 if dres is None else ld_of(dres), rows, c, groups, act)
-        _apply_stats_maybe_q8(q_site, dx, args, n, h, w, c)
-        return
-    if dg is not None:       # parameter gradients once per tensor (the chunk launches carry none)
-        tab = _e32(3, groups, c, device=x.device)
-        L.call("bg_norm_bwd_finalize", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, mean.data_ptr(),
-               rstd.data_ptr(), 1, tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr(), dg, db)
-    hw, ipg = h * w, n // groups
-    ldg, ldy_, ldx, lddx, lddr = ld_of(g), 0 if y is None else ld_of(y), ld_of(x), ld_of(dx), 0 if dres is None else ld_of(dres)
-    dxp, drp = dx.data_ptr(), None if dres is None else dres.data_ptr()
-
-    def run(n0, n1, g=g, y=y, x=x):      # (holds its inputs; not dx / dres, on which the note hangs)
-        g_, o = n0 // ipg, n0 * hw * es
-        L.call("bg_norm_act_bwd_apply_stats_part", dt, g.data_ptr() + o * ldg, ldg, None if y is None else y.data_ptr() + o * ldy_, ldy_,
-               x.data_ptr() + o * ldx, ldx, s[0][g_].data_ptr(), s[1][g_].data_ptr(), gptr, bptr, mean[g_].data_ptr(),
-               rstd[g_].data_ptr(), 1, dxp + o * lddx, lddx, None if drp is None else drp + o * lddr, lddr, (n1 - n0) * hw, c, act,
-               rows // groups)
-
-    d = Deferred(run, n, groups, ch, f"bn-apply-bwd {n}x{h}x{w}x{c}")
-    defer_on(dx, d)
-    if dres is not None:     # the residual gradient is written by the same launches: its reader must trigger them as well
-        _DEFERRED[dres.data_ptr()] = (__import__("weakref").ref(dres), d)
-        dres._bg_defer = d
-
-
 class NormActFn(torch.autograd.Function):
     """y = act( norm(x) + res ).
 
@@ -1233,31 +965,10 @@ class NormActFn(torch.autograd.Function):
                 L.call("bg_norm_stats", dt, x.data_ptr(), rows, c, ld_of(x), groups, s[0].data_ptr(), s[1].data_ptr())
             mean, rstd = _e32(2, groups, c, device=dev).unbind(0)
             upd = kind == "batch" and rmean is not None
-            es = x.element_size()
-            vec_ = 8 if x.dtype == torch.bfloat16 else 4
-            ch = (chunk_images(n, groups, h * w * ld_of(y) * es)
-                  if kind == "batch" and _is_nhwc(y, vec_) and _is_nhwc(x, vec_) and (res is None or _is_nhwc(res, vec_)) else 0)
-            if ch:
-                # too large to survive in the Infinity Cache until its reader runs: statistics finalised now, the apply pass
-                # left to that reader, chunk by chunk (Deferred; the arithmetic of the folded launch below)
-                scale, shift = _e32(2, groups, c, device=dev).unbind(0)
-                L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c, gptr, bptr, eps,
-                       momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                       rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
-                ldx, ldy, ldr, ipg, yp, hw = ld_of(x), ld_of(y), 0 if res is None else ld_of(res), n // groups, y.data_ptr(), h * w
-
-                def run(n0, n1, x=x, res=res):    # (holds x, res, scale, shift -- not y, on which the note hangs)
-                    g_ = n0 // ipg
-                    L.call("bg_norm_act_fwd", dt, x.data_ptr() + n0 * hw * ldx * es, ldx, scale[g_].data_ptr(), shift[g_].data_ptr(),
-                           None if res is None else res.data_ptr() + n0 * hw * ldr * es, ldr, yp + n0 * hw * ldy * es, ldy,
-                           (n1 - n0) * hw, c, 1, int(act))
-
-                defer_on(y, Deferred(run, n, groups, ch, f"bn-act {n}x{h}x{w}x{c}"))
-            else:
-                # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
-                L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
-                       momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
-                       rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
+            # finalize (mean/rstd, affine, running statistics) is folded into the apply kernel
+            L.call("bg_norm_act_fwd_stats", dt, x.data_ptr(), ld_of(x), s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, eps,
+                   momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None, mean.data_ptr(),
+                   rstd.data_ptr(), L.ptr(res), 0 if res is None else ld_of(res), y.data_ptr(), ld_of(y), rows, c, groups, int(act))
         else:
             if kind != "identity":  # BatchNorm in eval mode: affine from the running statistics
                 mean, rstd, scale, shift = _e32(4, groups, c, device=dev).unbind(0)
@@ -1301,8 +1012,9 @@ class NormActFn(torch.autograd.Function):
                     arena.ensure_grad(gslot)
                     arena.ensure_grad(bslot)
                     dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
-                _apply_bwd(dt, g, None, x, s, arena.master_ptr(gslot), arena.master_ptr(bslot), mean, rstd, dg, db, dx, None,
-                           n, h, w, c, groups, 0)
+                L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), None, 0, x.data_ptr(), ld_of(x),
+                       s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot), arena.master_ptr(bslot), mean.data_ptr(),
+                       rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), None, 0, rows, c, groups, 0)
             return (dx, g if need_res else None) + (None,) * 16
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
@@ -1330,15 +1042,11 @@ class NormActFn(torch.autograd.Function):
                 arena.ensure_grad(bslot)
                 dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
             # finalize (coefficients, dgamma/dbeta) is folded into the apply kernel
-            if batch_stats:
-                _apply_bwd(dt, g, None if yptr is None else y, x, s, gptr, bptr, mean, rstd, dg, db, dx, dres, n, h, w, c, groups,
-                           act, ctx.q_site if act else None)
-            else:
-                args = (dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
-                        s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
-                        0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
-                        0 if dres is None else ld_of(dres), rows, c, groups, act)
-                _apply_stats_maybe_q8(None, dx, args, *x.shape)
+            args = (dt, g.data_ptr(), ld_of(g), yptr, ld_of(y), x.data_ptr(), ld_of(x),
+                    s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
+                    1 if batch_stats else 0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
+                    0 if dres is None else ld_of(dres), rows, c, groups, act)
+            _apply_stats_maybe_q8(ctx.q_site if (batch_stats and act) else None, dx, args, *x.shape)
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
@@ -1378,24 +1086,7 @@ class NormActDwConvFn(torch.autograd.Function):
         upd = rmean is not None
         y = new_act(n, h, w, c, x.dtype, dev)
         desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(y))
-        es = x.element_size()
-        ch = chunk_images(n, groups, h * w * ld_of(y) * es) if _is_nhwc(y, 8 if x.dtype == torch.bfloat16 else 4) else 0
-        if ch:
-            # too large to survive in the Infinity Cache: the statistics are finalised now, the depthwise launches are left to
-            # the pointwise convolution that reads y, chunk by chunk (Deferred; same arithmetic as the folded launch below)
-            L.call("bg_norm_finalize_affine", s[0].data_ptr(), s[1].data_ptr(), rows // groups, groups, c,
-                   arena.master_ptr(gslot), arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None,
-                   rvar.data_ptr() if upd else None, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
-            ldx, ldy, wptr, ipg, yp = ld_of(x), ld_of(y), arena.weight_ptr(wslot), n // groups, y.data_ptr()
-
-            def run(n0, n1, x=x):     # (holds x, scale, shift -- not y, on which the note hangs)
-                g_ = n0 // ipg
-                d_ = L.DwDesc(dt, n1 - n0, h, w, c, h, w, 1, dil, ldx, ldy)
-                L.call("bg_dwconv3x3_fwd_pre", d_, x.data_ptr() + n0 * h * w * ldx * es, scale[g_].data_ptr(), shift[g_].data_ptr(), 1,
-                       int(act), wptr, yp + n0 * h * w * ldy * es)
-
-            defer_on(y, Deferred(run, n, groups, ch, f"bn-act-dw {n}x{h}x{w}x{c}"))
-        elif _FOLD_FINALIZE and c <= 4096:
+        if _FOLD_FINALIZE and c <= 4096:
             # the depthwise kernel finalises the statistics itself (no launch between the GEMM and it)
             L.call("bg_dwconv3x3_fwd_pre_stats", desc, x.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot),
                    arena.master_ptr(bslot), eps, momentum, rmean.data_ptr() if upd else None, rvar.data_ptr() if upd else None,
@@ -1415,10 +1106,6 @@ class NormActDwConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, mean, rstd, scale, shift = ctx.saved_tensors
         arena, gslot, bslot, wslot, act, groups, dil = ctx.meta
-        up = take_deferred(g) if _CHUNK_BWD else None    # a pending chain (BatchNorm apply -> pointwise data gradient) producing g
-        if up is not None and not _is_nhwc(g, 8 if g.dtype == torch.bfloat16 else 4):
-            up.run_all()
-            up = None
         g = nhwc(g)
         n, h, w, c = x.shape
         dev, dt = x.device, L.dt(x.dtype)
@@ -1431,9 +1118,6 @@ class NormActDwConvFn(torch.autograd.Function):
         fused = (_DW_FUSED_BWD and x.dtype == torch.bfloat16 and (need_dx or want_affine_grads)
                  and h * w * max(ld_of(x), ld_of(g)) * 2 < (1 << 31)
                  and (ctx.needs_input_grad[3] or (dil == 1 and rows * c >= 150_000_000)))
-        if up is not None and not fused:
-            up.run_all()
-            up = None
         if ctx.needs_input_grad[3]:
             arena.ensure_grad(wslot)
             if not fused:
@@ -1448,25 +1132,10 @@ class NormActDwConvFn(torch.autograd.Function):
         if fused:
             # ONE pass over g and x: the depthwise data gradient, the depthwise weight gradient on the recomputed activation
             # and the two statistics of the BatchNorm backward (three launches and six tensor passes in round 2)
-            dwp = arena.grad_ptr(wslot) if ctx.needs_input_grad[3] else None
-            if up is None:
-                desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-                L.call("bg_dwconv3x3_bwd_fused", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), scale.data_ptr(),
-                       shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), groups, act, da.data_ptr(), ld_of(da), dwp,
-                       s[0].data_ptr(), s[1].data_ptr())
-            else:
-                # the chain's chunk, then this unit's one-pass backward on it: the chunk of g comes out of the Infinity Cache
-                es, hw, ipg = x.element_size(), h * w, n // groups
-                for n0 in range(0, n, up.chunk):
-                    n1 = min(n, n0 + up.chunk)
-                    up.run(n0, n1)
-                    g_, o = n0 // ipg, n0 * hw * es
-                    dc = L.DwDesc(dt, n1 - n0, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
-                    L.call("bg_dwconv3x3_bwd_fused", dc, g.data_ptr() + o * ld_of(g), arena.weight_ptr(wslot), x.data_ptr() + o * ld_of(x),
-                           scale[g_].data_ptr(), shift[g_].data_ptr(), mean[g_].data_ptr(), rstd[g_].data_ptr(), 1, act,
-                           da.data_ptr() + o * ld_of(da), ld_of(da), dwp, s[0][g_].data_ptr(), s[1][g_].data_ptr())
-                up.done = True
-                up.finish()
+            desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(x), ld_of(g))
+            L.call("bg_dwconv3x3_bwd_fused", desc, g.data_ptr(), arena.weight_ptr(wslot), x.data_ptr(), scale.data_ptr(),
+                   shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), groups, act, da.data_ptr(), ld_of(da),
+                   arena.grad_ptr(wslot) if ctx.needs_input_grad[3] else None, s[0].data_ptr(), s[1].data_ptr())
         else:
             desc = L.DwDesc(dt, n, h, w, c, h, w, 1, dil, ld_of(da), ld_of(g))
             L.call("bg_dwconv3x3_bwd_data", desc, g.data_ptr(), arena.weight_ptr(wslot), da.data_ptr())
@@ -1478,7 +1147,10 @@ class NormActDwConvFn(torch.autograd.Function):
             arena.ensure_grad(bslot)
             dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
-        _apply_bwd(dt, da, None, x, s, gptr, bptr, mean, rstd, dg, db, dx, None, n, h, w, c, groups, act, ctx.q_site if act else None)
+        args = (dt, da.data_ptr(), ld_of(da), None, 0, x.data_ptr(), ld_of(x),
+                s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(), 1, dg, db, L.ptr(dx),
+                0 if dx is None else ld_of(dx), None, 0, rows, c, groups, act)
+        _apply_stats_maybe_q8(ctx.q_site if act else None, dx, args, n, h, w, c)
         return (dx,) + (None,) * 15
 
 
@@ -1499,7 +1171,6 @@ class ForkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k: int):
         ctx.k = k
-        flush_deferred(x)      # (several readers: the chunked schedule ends here)
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod
@@ -1572,7 +1243,6 @@ class GlobalAvgPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         n, nd, h, w, c, dtype = ctx.meta
-        flush_deferred(g)
         g = g.contiguous()
         gf = _f32(n, c, device=g.device)
         L.call("bg_cast_rows", L.dt(g.dtype), L.F32, g.data_ptr(), c, gf.data_ptr(), c, n, c)
@@ -1602,7 +1272,6 @@ class ConcatFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        flush_deferred(g)
         outs, off = [], 0
         for c in ctx.cs:
             outs.append(g[..., off:off + c])  # zero-copy channel slices; consumers honour the pixel stride

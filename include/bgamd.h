@@ -399,15 +399,6 @@ int bg_norm_act_bwd_apply_stats(int32_t dtype, const void* dy, int32_t lddy, con
                                 const float* mean, const float* rstd, int32_t train, float* dgamma, float* dbeta,
                                 void* dx, int32_t lddx, void* dres, int32_t lddres, int64_t rows, int32_t C,
                                 int32_t groups, int32_t act, void* stream);
-/* bg_norm_act_bwd_apply_stats over a PART of ONE statistic group's rows (an image chunk: the chunked schedule of
- * ops.Deferred runs apply(chunk), data-gradient GEMM(chunk), ... so that each chunk is read out of the Infinity Cache):
- * coefficients from the sums over stat_rows_per_group rows, `rows` (<= that) of them processed; s1 / s2 / mean / rstd point
- * at the group's row.  No dgamma / dbeta (bg_norm_bwd_finalize gives them once per tensor). */
-int bg_norm_act_bwd_apply_stats_part(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
-                                     int32_t ldx, const double* s1, const double* s2, const float* gamma, const float* beta,
-                                     const float* mean, const float* rstd, int32_t train, void* dx, int32_t lddx, void* dres,
-                                     int32_t lddres, int64_t rows, int32_t C, int32_t act, int64_t stat_rows_per_group,
-                                     void* stream);
 
 /* ---------------------------------------------------------------------------
  * Resampling / pooling / layout (deeplab.py:375,379,663 bilinear
