@@ -11,6 +11,7 @@ FAMILY = {  # kernel symbol fragment -> C-ABI entry points it implements
     "gemm_conv_dma_kernel": "bg_conv2d_fwd+bg_conv2d_bwd_data (64x64-per-wave tiles)",
     "wgrad_kernel": "bg_conv2d_bwd_weight",
     "dgrad_s2_smallc_kernel": "bg_conv2d_bwd_data(first layer: 3x3 stride 2, <= 16 channels)",
+    "dw_fork_bwd_kernel": "bg_dwconv3x3_bwd_fork (one pass: skip gradient + depthwise data / weight gradient + the producer's BatchNorm-backward statistics)",
     "dw_bwd_fused_kernel": "bg_dwconv3x3_bwd_fused (one pass: data gradient + weight gradient + BatchNorm-backward statistics)",
     "dw_ring_kernel": "bg_dwconv3x3_fwd(+_pre)+bg_dwconv3x3_bwd_data(stride 1, dilation 1/2: LDS prefetch ring)",
     "dw_s1_kernel": "bg_dwconv3x3_fwd+bg_dwconv3x3_bwd_data(stride 1, dilation 1)",
