@@ -929,6 +929,8 @@ int plan_fat(GemmConvParams& P, bool big) {   // big: an operand beyond the clas
     for (int c = 0; c < 4; ++c) {
         const int tm = cand[c][0], tnp = cand[c][1];
         if (tm == 384 && (!pw1 || sizeof(T) == 1)) continue;   // fp8: 56 registers of B fragments beside the accumulators
+        static const bool no384 = getenv("BGAMD_FAT_NO384") != nullptr;   // A/B (scripts/bench_corun.py): 256-row tiles leave room on the CU
+        if (tm == 384 && no384) continue;
         if ((tm == 128) != (P.NO <= 128)) continue;
         const long long tc = (P.NO + tm - 1) / tm, tp0 = groups * ((gp + tnp - 1) / tnp);
         const long long rounds = (tc * tp0 + NCU - 1) / NCU, cost = rounds * tm * tnp;
