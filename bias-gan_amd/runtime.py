@@ -57,6 +57,7 @@ class StatsPool:
     buffer that is cleared with ONE fill per training step (GANTrainer.step calls reset()),
     instead of one torch.zeros launch per normalisation layer and direction (~600 per step)."""
     _pools = {}
+    epoch = 0     # bumped by reset_all(): one per training iteration.  ops' hand-over notes are only valid inside one epoch.
 
     def __init__(self, device, n=1 << 22):
         self.buf = torch.zeros(n, dtype=torch.float64, device=device)
@@ -87,6 +88,7 @@ class StatsPool:
 
     @classmethod
     def reset_all(cls):
+        cls.epoch += 1
         for p in cls._pools.values():
             p.reset()
 

@@ -175,6 +175,40 @@ def build_discriminator(c, h, w, seed, dtype, norm=nn.BatchNorm2d, kind="batch")
     return D.to(DEV), spec
 
 
+def test_handover_notes_stay_inside_one_iteration():
+    """ops.ToInternal / FromInternal hand-over (round 4): the NHWC copy of an unchanged boundary tensor is reused INSIDE one
+    training iteration -- the generator's two forwards on one batch; the generator's output handed to the critic -- and never
+    across iterations (a loop that feeds the same tensor object again converts it again, as a run on fresh batches would),
+    nor after the tensor was written."""
+    from bias_gan_amd.runtime import StatsPool
+    L_ = __import__("bias_gan_amd._lib", fromlist=["x"])
+    x = torch.randn(2, 4, 16, 24, device=DEV)
+    count = lambda: [p_[0] for p_ in L_.PROFILE].count("bg_nchw_to_nhwc")   # noqa: E731
+    L_.PROFILE = []
+    try:
+        a = ops.ToInternal.apply(x, 8, BF16)
+        b = ops.ToInternal.apply(x, 8, BF16)
+        assert count() == 1 and a.data_ptr() == b.data_ptr()
+        StatsPool.reset_all()                              # the next iteration begins
+        c = ops.ToInternal.apply(x, 8, BF16)
+        assert count() == 2 and torch.equal(c, a)
+        x.add_(1.0)                                        # written: the note is stale
+        d = ops.ToInternal.apply(x, 8, BF16)
+        assert count() == 3 and not torch.equal(d, a)
+        y = ops.FromInternal.apply(d, 4)                   # module boundary out ...
+        z = ops.ToInternal.apply(y, 8, BF16)               # ... and into the next module: the internal bytes, no conversion
+        assert count() == 3 and z.data_ptr() == d.data_ptr()
+        ref = torch.zeros(2, 16, 24, 8, device=DEV, dtype=BF16)
+        ref[..., :4] = y.permute(0, 2, 3, 1).to(BF16)
+        assert torch.equal(z, ref)                         # the same bits a conversion would have produced (pad lanes zero)
+        StatsPool.reset_all()
+        z2 = ops.ToInternal.apply(y, 8, BF16)
+        assert count() == 4 and torch.equal(z2, ref)
+    finally:
+        L_.PROFILE = None
+    torch.cuda.synchronize()
+
+
 def test_fused_fork_backward_engages_in_the_middle_flow(monkeypatch):
     """The one-pass fork backward (bg_dwconv3x3_bwd_fork through ops.NormTail) is what the generator's middle-flow Blocks run
     in bf16, and switching it off (BGAMD_FORK_FUSED=0 semantics) gives the same gradients up to bf16 rounding of the
