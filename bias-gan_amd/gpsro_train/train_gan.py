@@ -82,6 +82,9 @@ class GANTrainer:
                     fake_g = self.generator(inputs)          # ONE forward, with graph: this step's only one
                 self._g_ahead = (inputs, fake_g, False)
                 outputs_fake = fake_g.detach()
+                note = getattr(fake_g, "_bg_internal", None)      # detach() is a new tensor object over the same bytes and version:
+                if note is not None:                               # carry the hand-over note (ops._internal_of) along
+                    outputs_fake._bg_internal = note
                 with ops.batch_groups(2):
                     logits, _ = self.discriminator((outputs_real, outputs_fake))
                 return self._d_update(logits[:n], logits[n:], outputs_fake, outputs_real, labels, eta)
