@@ -1288,6 +1288,23 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const T* __restr
 }
 
 
+template <typename T, int BKB, int NBUF, int TCH, int TP>
+int launch_small(GemmConvParams& P, hipStream_t st) {
+    P.tiles_c = (P.NO + TCH - 1) / TCH;
+    P.tiles_p = (int)((P.M + TP - 1) / TP);
+    const size_t sh = (size_t)NBUF * (TCH + TP) * BKB;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_dma_kernel<T, BKB, NBUF, TCH, TP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        once = true;
+    }
+    hipLaunchKernelGGL((gemm_conv_dma_kernel<T, BKB, NBUF, TCH, TP>), dim3((unsigned)(P.tiles_c * P.tiles_p)),
+                       dim3(TCH * TP / 64), sh, st, P);
+    BG_CHECK_LAUNCH("gemm_conv_dma_kernel(small)");
+    return BG_OK;
+}
+
 template <typename T>
 int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
     GemmConvParams P = P0;
@@ -1385,6 +1402,20 @@ int launch_gemm_conv(const GemmConvParams& P0, hipStream_t st, int splits = 1) {
     const int tp = (wide || flat) ? 256 : TILE;
     P.tiles_c = (P.NO + tch - 1) / tch;
     P.tiles_p = (int)((P.M + tp - 1) / tp);
+    // Few tiles (the 16 x 16 maps of the 256 x 256 configuration: 728 -> 728 on 2 048 pixels is 48 tiles of 256 x 128
+    // for 256 CUs): such a launch is bound by the latency of its K-steps, not by operand bytes.  128 x 128 tiles on
+    // twice the CUs, 128-byte rows (half the K-steps) and a 4-stage ring (three steps in flight): 16.5 -> 12.7 us for
+    // that launch with its statistics, 21.3 -> 16.7 for 1024 -> 1536, 29.5 -> 22.6 for 1536 -> 2048 (graph-replayed,
+    // scripts/bench_conv_one.py); 128 x 64 and 64 x 64 tiles were no faster on 728 channels and slower on the wider
+    // layers.  With a layer's weights cold (every launch another copy, beyond the Infinity Cache -- as in a training step)
+    // the old tiles take 18.6 us and these 13.5; touching the tile's whole weight panel ahead of the first K-step made
+    // both cases 0.8 us slower and the step 3 % (dropped).  Same K order per output element as every other tile shape.
+    // BGAMD_SMALL=0 switches it off (A/B).
+    static const bool small_on = !(getenv("BGAMD_SMALL") && atoi(getenv("BGAMD_SMALL")) == 0);
+    static const long long small_max = getenv("BGAMD_SMALL_MAX") ? atoll(getenv("BGAMD_SMALL_MAX")) : 128;
+    if (dma_mode == 1 && small_on && !wide && !flat && (long long)P.tiles_c * P.tiles_p <= small_max &&
+        P.stat_group_pix % TILE == 0)
+        return launch_small<T, 128, 4, TILE, TILE>(P, st);
     const long long nblk = (long long)P.tiles_c * P.tiles_p;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         bg_set_error("conv: grid too large");
