@@ -181,6 +181,79 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_kernel(Dw3Params P) {
     }
 }
 
+// The same two passes with every tap's load issued before the first is used.  The loops above skip taps outside the
+// volume with branches, so each tap's load waits for the one before it: 27 L2 round trips in a row, ~13 us per launch on
+// the 3 x 2 x 3 maps of the middle flow however little data there is.  Here a tap outside the volume is a buffer load at
+// the out-of-range offset (returns zeros, no branch), the three loops are unrolled and the compiler has a depth plane's
+// 18 loads in flight at once.  Same taps in the same order into the same fp32 accumulators: results as above.
+// 32-bit offsets over the whole tensor (the launcher keeps the pointer kernels for tensors of 2 GiB and more).
+template <typename T, bool DATA>
+__global__ __launch_bounds__(256) void dw3_taps_kernel(Dw3Params P, int a_bytes) {
+    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
+    typedef typename Elem<T>::vec_t vec_t;
+    const int cv = P.C / VEC;
+    // forward: the grid runs over the output (Do, Ho, Wo) and reads x (D, H, W); data gradient: over (D, H, W), reads dy
+    const int GD = DATA ? P.D : P.Do, GH = DATA ? P.H : P.Ho, GW = DATA ? P.W : P.Wo;
+    const int SD = DATA ? P.Do : P.D, SH = DATA ? P.Ho : P.H, SW = DATA ? P.Wo : P.W;
+    const int ld_src = DATA ? P.ldy : P.ldx, ldo = DATA ? P.ldx : P.ldy;
+    const long long total = (long long)P.N * GD * GH * GW * cv;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.a), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.b), 0, 27 * P.C * ES, 0x00020000);
+    const int s_w = ld_src * ES, s_h = SW * s_w, s_d = SH * s_h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / cv;
+        const int c = (int)(i - pix * cv) * VEC;
+        long long r = pix;
+        const int gw = (int)(r % GW); r /= GW;
+        const int gh = (int)(r % GH); r /= GH;
+        const int gd = (int)(r % GD);
+        const int n = (int)(r / GD);
+        int off[3][3];      // [axis][tap]: byte offset along the axis, or < 0 for a tap outside the volume
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int sd, sh, sw;
+            if (!DATA) {
+                sd = gd * P.stride - P.dil + k * P.dil;
+                sh = gh * P.stride - P.dil + k * P.dil;
+                sw = gw * P.stride - P.dil + k * P.dil;
+            } else {          // od * stride - dil + k * dil == id
+                const int td = gd + P.dil - k * P.dil, th = gh + P.dil - k * P.dil, tw = gw + P.dil - k * P.dil;
+                sd = td / P.stride; sh = th / P.stride; sw = tw / P.stride;
+                if (td < 0 || sd * P.stride != td) sd = -1;
+                if (th < 0 || sh * P.stride != th) sh = -1;
+                if (tw < 0 || sw * P.stride != tw) sw = -1;
+            }
+            off[0][k] = (unsigned)sd < (unsigned)SD ? sd * s_d : -1;
+            off[1][k] = (unsigned)sh < (unsigned)SH ? sh * s_h : -1;
+            off[2][k] = (unsigned)sw < (unsigned)SW ? sw * s_w : -1;
+        }
+        const int base = n * SD * s_d + c * ES;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            Chunk<T> av[9], wv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t % 3;
+                const int o = (off[0][kd] | off[1][kh] | off[2][kw]) < 0 ? (int)0x80000000
+                                                                         : base + off[0][kd] + off[1][kh] + off[2][kw];
+                av[t].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, o, 0, 0));
+                wv[t].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, ((kd * 9 + t) * P.C + c) * ES, 0, 0));
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fmaf(av[t].get(e), wv[t].get(e), acc[e]);
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+        o.store(reinterpret_cast<T*>(P.o) + pix * ldo + c);
+    }
+}
+
 // dw[kd,kh,kw,c] += sum dy * x.  Block = TX channel vectors x TY pixel lanes over a run of output (n,od,oh) rows;
 // one depth tap plane (9 taps) at a time keeps 9*VEC partials per thread; LDS fold, one float atomic per (tap, channel).
 struct Dw3WParams {
@@ -189,9 +262,12 @@ struct Dw3WParams {
     int rows_total, rows_per_block, tx, log_tx;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(Dw3WParams P) {
-    constexpr int VEC = Elem<T>::VEC;
+// BUF: the nine x loads of a gradient chunk as buffer loads (a tap outside the plane = the out-of-range offset, zeros) issued
+// together with it instead of one after the other behind branches; x_bytes / dy_bytes < 2 GiB (launcher).
+template <typename T, bool BUF>
+__global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(Dw3WParams P, int x_bytes, int dy_bytes) {
+    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
+    typedef typename Elem<T>::vec_t vec_t;
     __shared__ float red[256 * VEC];
     const int lx = threadIdx.x & (P.tx - 1);
     const int ly = threadIdx.x >> P.log_tx;
@@ -209,7 +285,39 @@ __global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(Dw3WParams P) {
     const int row0 = blockIdx.y * P.rows_per_block;
     int row1 = row0 + P.rows_per_block;
     if (row1 > P.rows_total) row1 = P.rows_total;
-    if (c_ok) {
+    if (BUF) {
+        // a block takes a run of rows_per_block output PIXELS (not rows: on the 3 x 2 x 3 maps a row is three pixels wide and
+        // the block's pixel lanes would idle); a pixel whose depth tap falls outside the volume loads zeros like any other
+        // out-of-range tap
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.x), 0, x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.dy), 0, dy_bytes, 0x00020000);
+        const int s_w = P.ldx * ES, s_h = P.W * s_w;
+        const int pix_total = P.rows_total * P.Wo;
+        const int p0 = blockIdx.y * P.rows_per_block;
+        const int p1 = min(p0 + P.rows_per_block, pix_total);
+#pragma unroll 2
+        for (int p = p0 + ly; p < p1; p += ty) {
+            const int ow = p % P.Wo, row = p / P.Wo;
+            const int oh = row % P.Ho, q = row / P.Ho;
+            const int od = q % P.Do, n = q / P.Do;
+            const int id = od * P.stride - P.dil + kd * P.dil;
+            const bool live = c_ok && (unsigned)id < (unsigned)P.D;
+            const int x_plane = (n * P.D + id) * P.H * s_h + c * ES;
+            Chunk<T> gv, xv[9];
+            gv.v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_g, live ? (p * P.ldy + c) * ES : (int)0x80000000, 0, 0));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t % 3;
+                const int ih = oh * P.stride - P.dil + kh * P.dil, iw = ow * P.stride - P.dil + kw * P.dil;
+                const bool ok = live && (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W;
+                xv[t].v = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? x_plane + ih * s_h + iw * s_w : (int)0x80000000, 0, 0));
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[t][e] = fmaf(gv.get(e), xv[t].get(e), acc[t][e]);
+        }
+    } else if (c_ok) {
         for (int row = row0; row < row1; ++row) {      // row = (n, od, oh), block-uniform
             const int oh = row % P.Ho;
             const int q = row / P.Ho;
@@ -404,13 +512,23 @@ extern "C" int bg_depth_fold(int32_t dtype, const void* dy, int32_t lddy, void* 
     return BG_OK;
 }
 
+static bool dw3_taps_on() {   // BGAMD_DW3_TAPS=0: the pointer kernels (A/B)
+    static const bool on = !(getenv("BGAMD_DW3_TAPS") && atoi(getenv("BGAMD_DW3_TAPS")) == 0);
+    return on;
+}
+
 extern "C" int bg_dwconv3x3x3_fwd(const bg_dwconv3d_desc* d, const void* x, const void* w, void* y, void* stream) {
     int rc = check_dw3(d, "bg_dwconv3x3x3_fwd");
     if (rc) return rc;
     BG_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w) && aligned16(y), "bg_dwconv3x3x3_fwd: null/unaligned pointer");
     Dw3Params P{x, w, y, d->N, d->D, d->H, d->W, d->C, d->Do, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy};
     const long long total = (long long)d->N * d->Do * d->Ho * d->Wo * (d->C / dtype_vec(d->dtype));
-    BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_fwd_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
+    const long long x_bytes = (((long long)d->N * d->D * d->H * d->W - 1) * d->ldx + d->C) * dtype_size(d->dtype);
+    if (dw3_taps_on() && x_bytes < 0x7fffffffLL)
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_taps_kernel<T, false>), dim3(grid1d(total)), dim3(256), 0,
+                                                          (hipStream_t)stream, P, (int)x_bytes));
+    else
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_fwd_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("dw3_fwd_kernel");
     return BG_OK;
 }
@@ -421,7 +539,12 @@ extern "C" int bg_dwconv3x3x3_bwd_data(const bg_dwconv3d_desc* d, const void* dy
     BG_CHECK_ARG(dy && w && dx && aligned16(dy) && aligned16(w) && aligned16(dx), "bg_dwconv3x3x3_bwd_data: null/unaligned pointer");
     Dw3Params P{dy, w, dx, d->N, d->D, d->H, d->W, d->C, d->Do, d->Ho, d->Wo, d->stride, d->dil, d->ldx, d->ldy};
     const long long total = (long long)d->N * d->D * d->H * d->W * (d->C / dtype_vec(d->dtype));
-    BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_bwd_data_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
+    const long long dy_bytes = (((long long)d->N * d->Do * d->Ho * d->Wo - 1) * d->ldy + d->C) * dtype_size(d->dtype);
+    if (dw3_taps_on() && dy_bytes < 0x7fffffffLL)
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_taps_kernel<T, true>), dim3(grid1d(total)), dim3(256), 0,
+                                                          (hipStream_t)stream, P, (int)dy_bytes));
+    else
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_bwd_data_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
     BG_CHECK_LAUNCH("dw3_bwd_data_kernel");
     return BG_OK;
 }
@@ -446,8 +569,24 @@ extern "C" int bg_dwconv3x3x3_bwd_weight(const bg_dwconv3d_desc* d, const void* 
     if (gy > P.rows_total) gy = P.rows_total;
     P.rows_per_block = (P.rows_total + gy - 1) / gy;
     gy = (P.rows_total + P.rows_per_block - 1) / P.rows_per_block;
-    BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_bwd_weight_kernel<T>), dim3(gx, (unsigned)gy, 3), dim3(256), 0,
-                                                      (hipStream_t)stream, P));
+    const long long x_bytes = (((long long)d->N * d->D * d->H * d->W - 1) * d->ldx + d->C) * dtype_size(d->dtype);
+    const long long dy_bytes = (((long long)d->N * d->Do * d->Ho * d->Wo - 1) * d->ldy + d->C) * dtype_size(d->dtype);
+    if (dw3_taps_on() && x_bytes < 0x7fffffffLL && dy_bytes < 0x7fffffffLL) {
+        // pixel runs: about 512 / gx blocks per depth tap, at least 4 pixels for each of a block's 256 / tx pixel lanes
+        Dw3WParams Q = P;
+        const long long pix = (long long)P.rows_total * d->Wo;
+        const int ty = 256 / best;
+        long long per = (pix + 512 / gx - 1) / std::max(1, 512 / gx);
+        per = std::max<long long>(per, 4 * ty);
+        per = (per + ty - 1) / ty * ty;
+        Q.rows_per_block = (int)per;
+        const unsigned gyp = (unsigned)((pix + per - 1) / per);
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_bwd_weight_kernel<T, true>), dim3(gx, gyp, 3), dim3(256), 0,
+                                                          (hipStream_t)stream, Q, (int)x_bytes, (int)dy_bytes));
+    }
+    else
+        BG_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((dw3_bwd_weight_kernel<T, false>), dim3(gx, (unsigned)gy, 3), dim3(256), 0,
+                                                          (hipStream_t)stream, P, 0, 0));
     BG_CHECK_LAUNCH("dw3_bwd_weight_kernel");
     return BG_OK;
 }
