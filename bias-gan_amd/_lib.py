@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("BGAMD_LIB") or os.path.join(_HERE, "libbgamd.so")   #
 
 BF16, F32, FP8 = 0, 1, 2
 FP8_E4M3, FP8_E5M2 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -114,6 +114,9 @@ _SIGS = {
     "bg_scale_rows": [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp],
     "bg_resize_nearest3d_fwd": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_resize_nearest3d_bwd": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_resize_trilinear3d_fwd": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_resize_trilinear3d_bwd": [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "bg_pc_dropout": [c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_f32, c_vp],
     "bg_blend_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "bg_tv_loss_fwd": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp],
     "bg_tv_loss_bwd": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],

@@ -64,8 +64,8 @@ class PConvUNet(BGModule):
     def __init__(self, layer_size=7, input_channels=3, output_channels=3, upsampling_mode='nearest', normalizer=nn.BatchNorm2d,
                  compute_dtype=None):
         super().__init__()
-        if upsampling_mode != 'nearest':
-            raise NotImplementedError("the HIP path builds upsampling_mode='nearest'")
+        if upsampling_mode not in ('nearest', 'bilinear'):
+            raise NotImplementedError("the HIP path builds upsampling_mode 'nearest' and 'bilinear'")
         self.freeze_enc_bn = False
         self.upsampling_mode, self.layer_size = upsampling_mode, layer_size
         self.input_channels, self.output_channels = input_channels, output_channels
@@ -100,7 +100,8 @@ class PConvUNet(BGModule):
         for i in range(self.layer_size, 0, -1):
             e, em = hs[i - 1], ms[i - 1]
             src, size = (1, h.shape[1], h.shape[2]), (1, e.shape[1], e.shape[2])
-            h = ops.NearestResize3dFn.apply(h, n, *size)
+            # 'bilinear' (align_corners unset, infill.py:193-195) = the trilinear kernel on volumes of depth 1
+            h = (ops.NearestResize3dFn if self.upsampling_mode == 'nearest' else ops.TrilinearResize3dFn).apply(h, n, *size)
             m = ops.nearest_rows(m, n, src, size)
             h, m = getattr(self, 'dec_{:d}'.format(i))([h, e], [m, em])
         hin, hin_mask = self.input_enc_1(x0, m0)

@@ -37,9 +37,12 @@ def partial_forward(conv, run_conv, xs, masks, n, planar):
     dims = (xs[0].shape[0] // n, xs[0].shape[1], xs[0].shape[2])
     rows = [m for m in masks if isinstance(m, ops.RowsMask)]
     full = [m for m in masks if not isinstance(m, ops.RowsMask)]
-    assert len(full) <= 1 and sum(m.channels for m in rows) <= conv.in_channels
-    upd, ratio, _ = ops.mask_window(n, dims, k, s, p, conv.eps, full[0] if full else None,
-                                    conv.in_channels - sum(m.channels for m in rows), rows, planar=planar)
+    assert sum(m.channels for m in rows) <= conv.in_channels
+    full_channels = conv.in_channels - sum(m.channels for m in rows)
+    if len(full) > 1:      # per-channel masks on both halves of a concatenation (after PCDropout3d): one tensor for the window sum
+        widths = [x.shape[3] for x, m in zip(xs, masks) if not isinstance(m, ops.RowsMask)]
+        full = [ops.concat_full_masks(full, widths[:-1] + [full_channels - sum(widths[:-1])])]
+    upd, ratio, _ = ops.mask_window(n, dims, k, s, p, conv.eps, full[0] if full else None, full_channels, rows, planar=planar)
     raw = run_conv(ops.MaskedConcatFn.apply(tuple(masks), *xs))
     a = conv.arena()
     bs = None if conv.bias is None else a.by_param[id(conv.bias)]
@@ -94,14 +97,44 @@ class PCBActiv3d(BGModule):
         return h, m
 
 
+class PCDropout3d(nn.Module):
+    """infill3d.py:115-135: nn.Dropout3d acts on the MASK (whole (sample, channel) maps with probability p); what it
+    dropped is zeroed in the input where the mask was valid and the input is rescaled by 1/(1-p).  Evaluation mode is
+    the identity.  The draw is keep[n][c] ~ Bernoulli(1-p) from torch's generator (the reference's own stream of
+    nn.Dropout3d cannot be reproduced); `inject` (a list of [N,C] 0/1 tensors, consumed call by call) replaces the
+    draw -- that is how the parity tests feed the reference's recorded draws."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p, self.scale = float(p), 1. - float(p)
+        self.inject = None
+
+    def draw(self, n, c, cp, device):
+        if self.inject:
+            k = self.inject.pop(0).to(device=device, dtype=torch.float32)
+            assert tuple(k.shape) == (n, c), f"injected keep mask {tuple(k.shape)} for a layer of {(n, c)}"
+        else:
+            k = torch.bernoulli(torch.full((n, c), self.scale, dtype=torch.float32, device=device))
+        if cp > c:
+            k = torch.cat([k, torch.ones(n, cp - c, dtype=torch.float32, device=device)], dim=1)
+        return k.contiguous()
+
+    def forward(self, h, mask, n, channels):
+        """h: folded features [N*D,H,W,Cp]; mask: RowsMask or per-channel folded tensor.  Returns (h_d, mask_d)."""
+        if not self.training:
+            return h, mask
+        keep = self.draw(n, channels, h.shape[3], h.device)
+        return ops.PCDropoutFn.apply(h, mask, keep, n, self.scale)
+
+
 class PConvUNet3d(BGModule):
-    """Partial-convolution U-Net (infill3d.py:135-239), upsampling_mode='nearest', dropout_p = 0."""
+    """Partial-convolution U-Net (infill3d.py:135-239): upsampling_mode 'nearest' or 'trilinear', optional PCDropout3d."""
 
     def __init__(self, layer_size=7, input_channels=3, output_channels=3, upsampling_mode='nearest',
                  normalizer=nn.BatchNorm3d, dropout_p=0., compute_dtype=None):
         super().__init__()
-        if upsampling_mode != 'nearest' or dropout_p > 0.:
-            raise NotImplementedError("the HIP path builds upsampling_mode='nearest' without dropout")
+        if upsampling_mode not in ('nearest', 'trilinear'):
+            raise NotImplementedError("the HIP path builds upsampling_mode 'nearest' and 'trilinear'")
         self.freeze_enc_bn = False
         self.upsampling_mode, self.layer_size = upsampling_mode, layer_size
         self.input_channels, self.output_channels = input_channels, output_channels
@@ -117,7 +150,7 @@ class PConvUNet3d(BGModule):
         self.dec_3 = PCBActiv3d(256 + 128, 128, activ='leaky', normalizer=normalizer)
         self.dec_2 = PCBActiv3d(128 + 64, 64, activ='leaky', normalizer=normalizer)
         self.dec_1 = PCBActiv3d(64 + input_channels, 32, activ='leaky', normalizer=normalizer)
-        self.dropout = None
+        self.dropout = PCDropout3d(p=dropout_p) if dropout_p > 0. else None
         self.last_conv = PCBActiv3d(32, output_channels, activ=None, normalizer=None, sample='point-1', conv_bias=True)
         for m in self.modules():    # __init_weights (infill3d.py:166-175): kaiming_normal_ convs, zero biases
             if isinstance(m, Conv3d):
@@ -134,15 +167,26 @@ class PConvUNet3d(BGModule):
         cp = pad_to(c, vec_of(dt))
         hs, ms = {0: to_folded(input, cp, dt)}, {0: to_folded(input_mask, cp, dt)}
         for i in range(1, self.layer_size + 1):
-            hs[i], ms[i] = getattr(self, 'enc_{:d}'.format(i))(hs[i - 1], ms[i - 1], n)
+            enc = getattr(self, 'enc_{:d}'.format(i))
+            hs[i], ms[i] = enc(hs[i - 1], ms[i - 1], n)
+            if self.dropout is not None:
+                hs[i], ms[i] = self.dropout(hs[i], ms[i], n, enc.conv.out_channels)
         h, m = hs[self.layer_size], ms[self.layer_size]
+        resize = ops.NearestResize3dFn if self.upsampling_mode == 'nearest' else ops.TrilinearResize3dFn
         for i in range(self.layer_size, 0, -1):
             e, em = hs[i - 1], ms[i - 1]
             src, size = (h.shape[0] // n, h.shape[1], h.shape[2]), (e.shape[0] // n, e.shape[1], e.shape[2])
-            h = ops.NearestResize3dFn.apply(h, n, *size)
-            m = ops.nearest_rows(m, n, src, size)
+            h = resize.apply(h, n, *size)
+            if isinstance(m, ops.RowsMask):        # the mask is resized with mode='nearest' whatever the features use (infill3d.py:221-222)
+                m = ops.nearest_rows(m, n, src, size)
+            else:
+                with torch.no_grad():
+                    m = ops.NearestResize3dFn.apply(m, n, *size)
             # torch.cat of the features and of the masks (infill3d.py:224-225) happens inside the layer
-            h, m = getattr(self, 'dec_{:d}'.format(i))([h, e], [m, em], n)
+            dec = getattr(self, 'dec_{:d}'.format(i))
+            h, m = dec([h, e], [m, em], n)
+            if self.dropout is not None:
+                h, m = self.dropout(h, m, n, dec.conv.out_channels)
         dims = (h.shape[0] // n, h.shape[1], h.shape[2])
         h, m = self.last_conv(h, m, n)
         return from_folded(h, n, self.output_channels), from_folded(mask_tensor(m, n, dims, self.output_channels, dt), n,

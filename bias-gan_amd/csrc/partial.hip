@@ -241,6 +241,153 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* m, const float*
     }
 }
 
+
+// PCDropout3d (infill3d.py:115-135) in training mode.  nn.Dropout3d zeroes whole (sample, channel) maps of the MASK
+// with probability p; keep[n][c] in {0, 1} is that draw (the 1/(1-p) rescaling cancels against `* self.scale` and the
+// round()).  mask_d = mask * keep; drop_vals = mask - mask_d; input_d = input * (1 - drop_vals) / scale.
+// The mask comes as one fp32 value per pixel (`rows`: an update_mask, whose channels are equal) or per channel (`m`).
+template <typename T>
+__global__ __launch_bounds__(256) void pc_dropout_kernel(const T* x, int ldx, const float* rows, const T* m, int ldm,
+                                                         const float* keep, int ldk, T* y, int ldy, T* mo, int ldmo,
+                                                         long long nrows, long long rows_per_sample, int C, float scale) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long total = nrows * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cv;
+        const int c = (int)(i - r * cv) * VEC;
+        const float* kp = keep + (r / rows_per_sample) * ldk + c;
+        Chunk<T> xv, mv, yo, mk;
+        xv.load(x + r * ldx + c);
+        if (m) mv.load(m + r * ldm + c);
+        const float mr = rows ? rows[r] : 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float mm = rows ? mr : mv.get(e);
+            const float md = mm * kp[e];
+            yo.set(e, xv.get(e) * (1.f - (mm - md)) / scale);
+            mk.set(e, md);
+        }
+        yo.store(y + r * ldy + c);
+        if (mo) mk.store(mo + r * ldmo + c);
+    }
+}
+
+// F.interpolate(size=..., mode='trilinear') as infill3d.py:217-220 calls it (align_corners unset = False): source
+// coordinate max(scale * (o + 0.5) - 0.5, 0) with scale = in / out in fp32, i0 = min((int)src, in - 1),
+// lambda1 = clamp(src - i0, 0, 1), i1 = i0 + (i0 < in - 1), and the identity where in == out (ATen's
+// compute_source_index_and_lambda).  The product and the difference are rounded separately (no fused multiply-add).
+__device__ __forceinline__ void tri_src(int o, int in, int out, float scale, int& i0, int& i1, float& l1) {
+    if (in == out) { i0 = i1 = o; l1 = 0.f; return; }
+    const float r = fmaxf(__fsub_rn(__fmul_rn(scale, (float)o + 0.5f), 0.5f), 0.f);
+    i0 = min((int)r, in - 1);
+    l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+}
+
+struct Tri3Params {
+    const void* x; void* y;        // fwd: x -> y; bwd: x = dy (output-sized), y = dx (input-sized)
+    int N, Di, Hi, Wi, Do, Ho, Wo, C, ldx, ldy;
+    float sd, sh, sw;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void trilinear3d_fwd_kernel(Tri3Params P) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = P.C / VEC;
+    const long long total = (long long)P.N * P.Do * P.Ho * P.Wo * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / cv;
+        const int c = (int)(i - pix * cv) * VEC;
+        long long r = pix;
+        const int ow = (int)(r % P.Wo); r /= P.Wo;
+        const int oh = (int)(r % P.Ho); r /= P.Ho;
+        const int od = (int)(r % P.Do);
+        const int n = (int)(r / P.Do);
+        int d0, d1, h0, h1, w0, w1;
+        float ld1, lh1, lw1;
+        tri_src(od, P.Di, P.Do, P.sd, d0, d1, ld1);
+        tri_src(oh, P.Hi, P.Ho, P.sh, h0, h1, lh1);
+        tri_src(ow, P.Wi, P.Wo, P.sw, w0, w1, lw1);
+        const T* xb = reinterpret_cast<const T*>(P.x) + (long long)n * P.Di * P.Hi * P.Wi * P.ldx + c;
+        auto at = [&](int d, int h, int w) {
+            Chunk<T> v;
+            v.load(xb + (((long long)d * P.Hi + h) * P.Wi + w) * P.ldx);
+            return v;
+        };
+        const Chunk<T> v000 = at(d0, h0, w0), v001 = at(d0, h0, w1), v010 = at(d0, h1, w0), v011 = at(d0, h1, w1);
+        const Chunk<T> v100 = at(d1, h0, w0), v101 = at(d1, h0, w1), v110 = at(d1, h1, w0), v111 = at(d1, h1, w1);
+        const float ld0 = 1.f - ld1, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float a = ld0 * (lh0 * (lw0 * v000.get(e) + lw1 * v001.get(e)) + lh1 * (lw0 * v010.get(e) + lw1 * v011.get(e))) +
+                            ld1 * (lh0 * (lw0 * v100.get(e) + lw1 * v101.get(e)) + lh1 * (lw0 * v110.get(e) + lw1 * v111.get(e)));
+            o.set(e, a);
+        }
+        o.store(reinterpret_cast<T*>(P.y) + pix * P.ldy + c);
+    }
+}
+
+// the outputs along one axis that read input index i: a window around the inverse of the source map, every candidate
+// checked with the forward's own arithmetic (so this is the exact adjoint); weight = (i0 == i) * l0 + (i1 == i) * l1
+__device__ __forceinline__ void tri_range(int i, int in, int out, float scale, int& lo, int& hi) {
+    if (in == out) { lo = hi = i; return; }
+    const float inv = (float)out / (float)in;
+    lo = max(0, (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1);
+    hi = min(out - 1, (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1);
+}
+__device__ __forceinline__ float tri_weight(int o, int i, int in, int out, float scale) {
+    int i0, i1;
+    float l1;
+    tri_src(o, in, out, scale, i0, i1, l1);
+    return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trilinear3d_bwd_kernel(Tri3Params P) {   // gather per INPUT voxel: no atomics, deterministic
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = P.C / VEC;
+    const long long total = (long long)P.N * P.Di * P.Hi * P.Wi * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / cv;
+        const int c = (int)(i - pix * cv) * VEC;
+        long long r = pix;
+        const int iw = (int)(r % P.Wi); r /= P.Wi;
+        const int ih = (int)(r % P.Hi); r /= P.Hi;
+        const int id = (int)(r % P.Di);
+        const int n = (int)(r / P.Di);
+        int dlo, dhi, hlo, hhi, wlo, whi;
+        tri_range(id, P.Di, P.Do, P.sd, dlo, dhi);
+        tri_range(ih, P.Hi, P.Ho, P.sh, hlo, hhi);
+        tri_range(iw, P.Wi, P.Wo, P.sw, wlo, whi);
+        const T* gb = reinterpret_cast<const T*>(P.x) + (long long)n * P.Do * P.Ho * P.Wo * P.ldx + c;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int od = dlo; od <= dhi; ++od) {
+            const float wd = tri_weight(od, id, P.Di, P.Do, P.sd);
+            if (wd == 0.f) continue;
+            for (int oh = hlo; oh <= hhi; ++oh) {
+                const float wh = wd * tri_weight(oh, ih, P.Hi, P.Ho, P.sh);
+                if (wh == 0.f) continue;
+                for (int ow = wlo; ow <= whi; ++ow) {
+                    const float ww = wh * tri_weight(ow, iw, P.Wi, P.Wo, P.sw);
+                    if (ww == 0.f) continue;
+                    Chunk<T> g;
+                    g.load(gb + (((long long)od * P.Ho + oh) * P.Wo + ow) * P.ldx);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = fmaf(ww, g.get(e), acc[e]);
+                }
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+        o.store(reinterpret_cast<T*>(P.y) + pix * P.ldy + c);
+    }
+}
+
 }  // namespace
 
 extern "C" int bg_blend_f32(const float* m, const float* a, const float* b, float* y, int64_t n, void* stream) {
@@ -358,5 +505,54 @@ extern "C" int bg_tv_loss_bwd(const float* x, int64_t A, int32_t D, int32_t H, i
     hipLaunchKernelGGL(tv_bwd_kernel, dim3(grid1d(A * D * H * W)), dim3(256), 0, (hipStream_t)stream, x, (long long)A, D, H, W, inv_h,
                        inv_d, coef, dx);
     BG_CHECK_LAUNCH("tv_bwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_pc_dropout(int32_t dtype, const void* x, int32_t ldx, const float* rows, const void* mask, int32_t ldm,
+                             const float* keep, int32_t ldk, void* y, int32_t ldy, void* mask_out, int32_t ldmo, int64_t nrows,
+                             int64_t rows_per_sample, int32_t C, float scale, void* stream) {
+    BG_CHECK_ARG(dtype_ok(dtype) && x && keep && y && aligned16(x) && aligned16(y) && ((rows != nullptr) != (mask != nullptr)) &&
+                     (!mask || aligned16(mask)) && (!mask_out || aligned16(mask_out)),
+                 "bg_pc_dropout: bad dtype / pointer (exactly one of rows / mask)");
+    const int vec = dtype_vec(dtype);
+    BG_CHECK_ARG(nrows > 0 && rows_per_sample > 0 && nrows % rows_per_sample == 0 && C > 0 && C % vec == 0 && ldx % vec == 0 &&
+                     ldy % vec == 0 && ldx >= C && ldy >= C && ldk >= C && (!mask || (ldm % vec == 0 && ldm >= C)) &&
+                     (!mask_out || (ldmo % vec == 0 && ldmo >= C)) && scale > 0.f && scale <= 1.f,
+                 "bg_pc_dropout: bad sizes (C/ld multiples of %d, 0 < scale <= 1)", vec);
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((pc_dropout_kernel<T>), dim3(grid1d(nrows * (C / vec))), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, ldx, rows, (const T*)mask, ldm, keep, ldk, (T*)y,
+                                                   ldy, (T*)mask_out, ldmo, (long long)nrows, (long long)rows_per_sample, C, scale));
+    BG_CHECK_LAUNCH("pc_dropout_kernel");
+    return BG_OK;
+}
+
+static int tri3_params(Tri3Params& P, int32_t dtype, const void* a, int32_t lda, void* b, int32_t ldb, int N, int Di, int Hi, int Wi,
+                       int Do, int Ho, int Wo, int C, const char* who) {
+    // a / lda: the tensor read (x forward, dy backward); b / ldb: the tensor written
+    int rc = check_nearest(dtype, a, b, N, Di, Hi, Wi, Do, Ho, Wo, C, lda, ldb, who);
+    if (rc) return rc;
+    P = Tri3Params{a, b, N, Di, Hi, Wi, Do, Ho, Wo, C, lda, ldb, (float)Di / (float)Do, (float)Hi / (float)Ho, (float)Wi / (float)Wo};
+    return BG_OK;
+}
+
+extern "C" int bg_resize_trilinear3d_fwd(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Di,
+                                         int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
+    Tri3Params P;
+    int rc = tri3_params(P, dtype, x, ldx, y, ldy, N, Di, Hi, Wi, Do, Ho, Wo, C, "bg_resize_trilinear3d_fwd");
+    if (rc) return rc;
+    const long long total = (long long)N * Do * Ho * Wo * (C / dtype_vec(dtype));
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((trilinear3d_fwd_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
+    BG_CHECK_LAUNCH("trilinear3d_fwd_kernel");
+    return BG_OK;
+}
+
+extern "C" int bg_resize_trilinear3d_bwd(int32_t dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N, int32_t Di,
+                                         int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
+    Tri3Params P;
+    int rc = tri3_params(P, dtype, dy, lddy, dx, lddx, N, Di, Hi, Wi, Do, Ho, Wo, C, "bg_resize_trilinear3d_bwd");
+    if (rc) return rc;
+    const long long total = (long long)N * Di * Hi * Wi * (C / dtype_vec(dtype));
+    BG_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((trilinear3d_bwd_kernel<T>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, P));
+    BG_CHECK_LAUNCH("trilinear3d_bwd_kernel");
     return BG_OK;
 }

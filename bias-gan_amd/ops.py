@@ -1585,6 +1585,77 @@ class NearestResize3dFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class TrilinearResize3dFn(torch.autograd.Function):
+    """F.interpolate(size=(do,ho,wo), mode='trilinear') with align_corners unset (= False) on a folded volume: what
+    PConvUNet3d(upsampling_mode='trilinear') applies to the features (infill3d.py:217-220)."""
+
+    @staticmethod
+    def forward(ctx, x, n, do, ho, wo):
+        x = nhwc(x)
+        nd, hi, wi, c = x.shape
+        di = nd // n
+        y = new_act(n * do, ho, wo, c, x.dtype, x.device)
+        L.call("bg_resize_trilinear3d_fwd", L.dt(x.dtype), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n, di, hi, wi, do, ho, wo, c)
+        ctx.meta = (n, di, hi, wi, do, ho, wo, c, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, di, hi, wi, do, ho, wo, c, dtype = ctx.meta
+        g = nhwc(g)
+        dx = new_act(n * di, hi, wi, c, dtype, g.device)
+        L.call("bg_resize_trilinear3d_bwd", L.dt(dtype), g.data_ptr(), ld_of(g), dx.data_ptr(), ld_of(dx), n, di, hi, wi, do, ho, wo, c)
+        return dx, None, None, None, None
+
+
+class PCDropoutFn(torch.autograd.Function):
+    """PCDropout3d.forward in training mode (infill3d.py:119-131) for a given draw keep[n][c] of nn.Dropout3d:
+    returns (input_d, mask_d) with mask_d a per-channel folded tensor.  mask: RowsMask or a folded per-channel tensor."""
+
+    @staticmethod
+    def forward(ctx, x, mask, keep, n, scale):
+        x = nhwc(x)
+        nd, h, w, c = x.shape
+        rows = nd * h * w
+        y = new_act(nd, h, w, c, x.dtype, x.device)
+        mo = new_act(nd, h, w, c, x.dtype, x.device)
+        ctx.mask = mask if isinstance(mask, RowsMask) else nhwc(mask)
+        ctx.keep, ctx.meta = keep, (rows, rows // n, c, float(scale))
+        PCDropoutFn._run(x, ctx.mask, keep, y, mo, *ctx.meta)
+        ctx.mark_non_differentiable(mo)
+        return y, mo
+
+    @staticmethod
+    def _run(x, mask, keep, y, mo, rows, per_sample, c, scale):
+        assert keep.dtype == torch.float32 and keep.shape[1] >= c and keep.is_contiguous()
+        is_rows = isinstance(mask, RowsMask)
+        L.call("bg_pc_dropout", L.dt(x.dtype), x.data_ptr(), ld_of(x), mask.rows.data_ptr() if is_rows else None,
+               None if is_rows else mask.data_ptr(), 0 if is_rows else ld_of(mask), keep.data_ptr(), keep.shape[1], y.data_ptr(),
+               ld_of(y), L.ptr(mo), 0 if mo is None else ld_of(mo), rows, per_sample, c, scale)
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        g = nhwc(g)
+        dx = new_act(*g.shape, g.dtype, g.device)
+        PCDropoutFn._run(g, ctx.mask, ctx.keep, dx, None, *ctx.meta)
+        return dx, None, None, None, None
+
+
+def concat_full_masks(masks, reals):
+    """torch.cat of per-channel folded masks along the channels (infill3d.py:225) as row-slice copies; reals[i] = real
+    channels of masks[i] (every segment but the last must fill its padded width)."""
+    masks = [nhwc(m) for m in masks]
+    assert all(m.shape[3] == r for m, r in zip(masks[:-1], reals[:-1]))
+    n, h, w, _ = masks[0].shape
+    out = new_act(n, h, w, sum(m.shape[3] for m in masks), masks[0].dtype, masks[0].device)
+    off, es = 0, out.element_size()
+    for m in masks:
+        L.call("bg_cast_rows", L.dt(m.dtype), L.dt(out.dtype), m.data_ptr(), ld_of(m), out.data_ptr() + off * es, ld_of(out),
+               n * h * w, m.shape[3])
+        off += m.shape[3]
+    return out
+
+
 class TVLossCompFn(torch.autograd.Function):
     """total_variation_loss(mask*input + (1-mask)*output) of InpaintingLoss (utils/losses.py:40-44,71,97) on
     contiguous fp32 [N,C,D,H,W] tensors (shifts along H and D, as the reference's 4-D function acts on them) or

@@ -55,7 +55,7 @@ extern "C" {
 #define BG_E_ARG (-1)    /* bad argument / shape the kernels do not support */
 #define BG_E_LAUNCH (-2) /* hipLaunch failed (message carries hipGetErrorString) */
 
-#define BG_ABI_VERSION 2
+#define BG_ABI_VERSION 3
 
 int bg_abi_version(void);
 const char* bg_last_error(void);
@@ -307,6 +307,13 @@ int bg_depth_avg2(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ld
  *   Both are their own adjoints w.r.t. x.
  * bg_resize_nearest3d_*: F.interpolate(size=..., mode='nearest') (infill3d.py:217-222), source index
  *   floor(dst * in / out); _bwd is the adjoint (overwrites dx).
+ * bg_resize_trilinear3d_*: F.interpolate(size=..., mode='trilinear') as PConvUNet3d(upsampling_mode='trilinear') calls it
+ *   (infill3d.py:217-220; align_corners unset = False): source coordinate max(in/out * (o + 0.5) - 0.5, 0) per axis,
+ *   identity where in == out; _bwd gathers per input voxel (the exact adjoint, no atomics; overwrites dx).
+ * bg_pc_dropout: PCDropout3d.forward in training mode (infill3d.py:115-135) with the nn.Dropout3d draw handed in as
+ *   keep[n][c] in {0,1} (fp32, row stride ldk): mask_out = mask * keep, y = x * (1 - (mask - mask_out)) / scale with
+ *   scale = 1 - p.  The mask is EITHER `rows` (fp32 per pixel: an update_mask, whose channels are equal) OR `mask` (a
+ *   per-channel tensor); mask_out may be NULL (the adjoint w.r.t. x is the same call on the gradient).
  * bg_tv_loss_*: total_variation_loss (utils/losses.py:40-44) as it acts on a contiguous fp32 5-D tensor viewed as
  *   [A][D][H][W]: mean |shift along H| + mean |shift along D|; loss accumulated (caller zeroes), dx = coef[0] * d loss/dx.
  * ------------------------------------------------------------------------- */
@@ -323,6 +330,13 @@ int bg_resize_nearest3d_fwd(int32_t dtype, const void* x, int32_t ldx, void* y, 
                             int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream);
 int bg_resize_nearest3d_bwd(int32_t dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N, int32_t Di,
                             int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int bg_resize_trilinear3d_fwd(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t Di, int32_t Hi,
+                              int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int bg_resize_trilinear3d_bwd(int32_t dtype, const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t N, int32_t Di,
+                              int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int bg_pc_dropout(int32_t dtype, const void* x, int32_t ldx, const float* rows, const void* mask, int32_t ldm, const float* keep,
+                  int32_t ldk, void* y, int32_t ldy, void* mask_out, int32_t ldmo, int64_t nrows, int64_t rows_per_sample,
+                  int32_t C, float scale, void* stream);
 /* y = m*a + (1-m)*b on flat fp32 arrays (output_comp, utils/losses.py:71); a == NULL: y = (1-m)*b (its adjoint w.r.t. b). */
 int bg_blend_f32(const float* m, const float* a, const float* b, float* y, int64_t n, void* stream);
 int bg_tv_loss_fwd(const float* x, int64_t A, int32_t D, int32_t H, int32_t W, float* loss, void* stream);

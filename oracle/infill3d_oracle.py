@@ -69,15 +69,16 @@ def unet2d_spec(cin: int, cout: int, layer_size: int = 7, norm_kind: str = "batc
     return s
 
 
-def unet2d(P: State, x, mask, layer_size: int, ctx: NormCtx):
-    """2-D PConvUNet.forward (infill.py:165-210), upsampling_mode='nearest'."""
+def unet2d(P: State, x, mask, layer_size: int, ctx: NormCtx, upsampling_mode: str = "nearest"):
+    """2-D PConvUNet.forward (infill.py:165-210); upsampling_mode 'nearest' | 'bilinear' for the features (:193-195), the
+    mask always 'nearest' (:196-198)."""
     hs, ms = {0: x}, {0: mask}
     for i in range(1, layer_size + 1):
         hs[i], ms[i] = pcb_activ(P, f"enc_{i}", hs[i - 1], ms[i - 1], 3, 2, 1, i != 1, "relu", ctx)
     h, m = hs[layer_size], ms[layer_size]
     for i in range(layer_size, 0, -1):
         size = tuple(hs[i - 1].shape[2:])
-        h = F.interpolate(h, size=size, mode="nearest")
+        h = F.interpolate(h, size=size, mode=upsampling_mode)
         m = F.interpolate(m, size=size, mode="nearest")
         h, m = pcb_activ(P, f"dec_{i}", torch.cat([h, hs[i - 1]], dim=1), torch.cat([m, ms[i - 1]], dim=1), 3, 1, 1, True,
                          "leaky", ctx)
@@ -127,19 +128,36 @@ def pcb_activ(P: State, key: str, x, mask, k, stride, pad, has_norm, act, ctx: N
     return h, m
 
 
-def unet3d(P: State, x, mask, layer_size: int, ctx: NormCtx):
-    """PConvUNet3d.forward (infill3d.py:177-239), upsampling_mode='nearest', no dropout."""
+def pc_dropout3d(x, mask, keep, p: float):
+    """PCDropout3d.forward in training mode (infill3d.py:119-131) for a given draw of its nn.Dropout3d: keep [N,C] in {0,1}
+    (Dropout3d zeroes whole (sample, channel) maps of the MASK with probability p and scales the rest by 1/(1-p))."""
+    scale = 1.0 - p
+    dropped = mask * keep.view(keep.shape[0], keep.shape[1], 1, 1, 1) / scale      # self.dropout(mask)
+    mask_d = torch.round(dropped * scale)
+    drop_vals = mask - mask_d
+    return x * (1.0 - drop_vals) / scale, mask_d
+
+
+def unet3d(P: State, x, mask, layer_size: int, ctx: NormCtx, upsampling_mode: str = "nearest", dropout_p: float = 0.0, keeps=None):
+    """PConvUNet3d.forward (infill3d.py:177-239).  upsampling_mode: 'nearest' | 'trilinear' (the mask is always resized
+    with 'nearest', :221-222).  dropout_p > 0 (training mode): `keeps` lists the Dropout3d draws [N,C] in call order --
+    one per encoder layer, then one per decoder layer."""
+    keeps = list(keeps) if keeps is not None else None
     hs, ms = {0: x}, {0: mask}
     for i in range(1, layer_size + 1):
         hs[i], ms[i] = pcb_activ(P, f"enc_{i}", hs[i - 1], ms[i - 1], 3, 2, 1, i != 1, "relu", ctx)
+        if dropout_p > 0.0:
+            hs[i], ms[i] = pc_dropout3d(hs[i], ms[i], keeps.pop(0), dropout_p)
     h, m = hs[layer_size], ms[layer_size]
     for i in range(layer_size, 0, -1):
         size = tuple(hs[i - 1].shape[2:])
-        h = F.interpolate(h, size=size, mode="nearest")
+        h = F.interpolate(h, size=size, mode=upsampling_mode)
         m = F.interpolate(m, size=size, mode="nearest")
         h = torch.cat([h, hs[i - 1]], dim=1)
         m = torch.cat([m, ms[i - 1]], dim=1)
         h, m = pcb_activ(P, f"dec_{i}", h, m, 3, 1, 1, True, "leaky", ctx)
+        if dropout_p > 0.0:
+            h, m = pc_dropout3d(h, m, keeps.pop(0), dropout_p)
     return pcb_activ(P, "last_conv", h, m, 1, 1, 0, False, None, ctx)
 
 

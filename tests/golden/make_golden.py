@@ -632,6 +632,44 @@ def golden_infill3d(cin=2, cout=1, d=32, h=24, w=40, n=2, g_layers=4, d_layers=5
     print("infill3d goldens written:", {k_: float(res["g::loss_" + k_]) for k_ in ("hole", "valid", "tv")})
 
 
+def golden_infill3d_options(cin=2, cout=1, d=18, h=10, w=14, n=2, g_layers=4, p_drop=0.25):
+    """PConvUNet3d's two options off the GAN path (infill3d.py:139-142): upsampling_mode='trilinear' (odd sizes: source
+    maps with scales 2/3, 3/5, 5/9, 4/7 besides 1/2) and dropout_p > 0 (PCDropout3d in training mode).  The draws of
+    the reference's nn.Dropout3d are RECORDED by a forward hook -- keep[n][c] = the mask map survived -- so that the
+    oracle and the HIP path can be handed the same draw; maps whose mask is all zero have no observable draw (and none
+    matters: mask * keep = 0 either way) and are recorded as kept."""
+    res = {}
+    x, gt, mask = orci.synthetic_infill(n, cin, d, h, w, 161)
+    for tag, kw in (("tri", dict(upsampling_mode="trilinear")), ("drop", dict(upsampling_mode="nearest", dropout_p=p_drop)),
+                    ("tridrop", dict(upsampling_mode="trilinear", dropout_p=p_drop))):
+        g = ref_infill.Generator(layer_size=g_layers, input_channels=cin, output_channels=cout, normalizer=nn.BatchNorm3d, **kw)
+        _load_checked(g, orci.unet3d_spec(cin, cout, g_layers), 53)
+        g.train()
+        keeps = []
+        if g.dropout is not None:
+            def hook(_m, inp, out):
+                alive = inp[0].flatten(2).amax(dim=2) > 0
+                keeps.append(torch.where(alive, (out.flatten(2).amax(dim=2) > 0).float(), torch.ones_like(alive, dtype=torch.float32)))
+            g.dropout.dropout.register_forward_hook(hook)
+        torch.manual_seed(1234)
+        out, out_mask = g(x, mask)
+        ld = ref_losses.InpaintingLoss(loss_type="smooth-l1")(x[:, :cout], out, gt[:, :cout], mask[:, :cout])
+        (6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]).backward()
+        res[tag + "::out"], res[tag + "::out_mask"] = out.detach().numpy(), out_mask.detach().numpy()
+        for i, k_ in enumerate(keeps):
+            res[f"{tag}::keep_{i}"] = k_.numpy()
+        res[tag + "::n_keeps"] = np.array(len(keeps))
+        cs = checksums((k, p_.grad) for k, p_ in g.named_parameters())
+        res[tag + "::grad_keys"], res[tag + "::grad_cs"] = np.array(list(cs.keys())), np.stack(list(cs.values()))
+        named = dict(g.named_parameters())
+        for k in ("enc_1.conv.weight", "enc_2.bn.weight", "dec_1.conv.weight", "dec_2.bn.bias", "last_conv.conv.bias"):
+            res[f"{tag}::grad::" + k] = named[k].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"infill3d_options_c{cin}_{d}x{h}x{w}.npz"),
+                        meta=json.dumps(dict(cin=cin, cout=cout, d=d, h=h, w=w, n=n, g_layers=g_layers, p_drop=p_drop, g_seed=53,
+                                             field_seed=161)), **res)
+    print("infill3d option goldens written:", {t: int(res[t + "::n_keeps"]) for t in ("tri", "drop", "tridrop")})
+
+
 def golden_infill_trajectory(d=32, h=24, w=40, n=2, g_layers=4, d_layers=5, steps=7, warmup=1, acc_min=0.55, acc_max=0.8,
                              lr=1e-3, wd=0.01, adam_eps=1e-4):
     """Seven iterations of the loop body infill3d_gan_module.py:272-375 driven on the reference's Generator,
@@ -715,11 +753,12 @@ def golden_infill_trajectory(d=32, h=24, w=40, n=2, g_layers=4, d_layers=5, step
              field_seed0=2000, noise_seed0=3000, loss_type="l2")), **out)
 
 
-def golden_infill2d(c=2, h=40, w=56, n=2, layers=4):
+def golden_infill2d(c=2, h=40, w=56, n=2, layers=4, mode="nearest"):
     """2-D partial-convolution U-Net (infill.py, partialconv2d.py; SURVEY 8(f)-4 "2-D shapes") + the inpainting loss on
-    4-D tensors (its total-variation term then shifts along W and H)."""
+    4-D tensors (its total-variation term then shifts along W and H).  mode: upsampling_mode of the features
+    ('bilinear': a second file, on sizes whose halvings are odd -- 22 x 26 -> 11 x 13 -> 6 x 7 -> 3 x 4 -> 2 x 2)."""
     res = {}
-    g = ref_infill2d.PConvUNet(layer_size=layers, input_channels=c, output_channels=c, upsampling_mode="nearest",
+    g = ref_infill2d.PConvUNet(layer_size=layers, input_channels=c, output_channels=c, upsampling_mode=mode,
                                normalizer=nn.BatchNorm2d)
     spec = orci.unet2d_spec(c, c, layers)
     _load_checked(g, spec, 71)
@@ -743,8 +782,8 @@ def golden_infill2d(c=2, h=40, w=56, n=2, layers=4):
     sd = g.state_dict()
     for k in ("enc_2.bn.running_mean", "input_enc_1.bn.running_var"):
         res["buf::" + k] = sd[k].numpy()
-    np.savez_compressed(os.path.join(HERE, f"infill2d_c{c}_{h}x{w}.npz"),
-                        meta=json.dumps(dict(c=c, h=h, w=w, n=n, layers=layers, seed=71, field_seed=171)), **res)
+    np.savez_compressed(os.path.join(HERE, f"infill2d_c{c}_{h}x{w}.npz" if mode == "nearest" else f"infill2d_{mode}_c{c}_{h}x{w}.npz"),
+                        meta=json.dumps(dict(c=c, h=h, w=w, n=n, layers=layers, seed=71, field_seed=171, mode=mode)), **res)
     print("infill2d goldens written:", {k_: float(res["loss_" + k_]) for k_ in ("hole", "valid", "tv")})
 
 
@@ -752,10 +791,14 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     if "all" in which or "infill3d" in which:
         golden_infill3d()
+    if "all" in which or "infill3d_options" in which:
+        golden_infill3d_options()
     if "all" in which or "gan3d_deconv" in which:
         golden_gan3d_deconv()
     if "all" in which or "infill2d" in which:
         golden_infill2d()
+    if "all" in which or "infill2d_bilinear" in which:
+        golden_infill2d(h=22, w=26, mode="bilinear")
     if "all" in which or "infill3d_trajectory" in which:
         golden_infill_trajectory()
     if "all" in which or "gan3d" in which:

@@ -143,6 +143,95 @@ def test_nearest_resize3d(dtype, size):
     close(xd.grad.cpu(), x.grad, tol(dtype), "dx")
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("src,size", [((4, 3, 5), (8, 6, 10)), ((3, 2, 2), (5, 3, 4)), ((5, 3, 4), (9, 5, 7)), ((2, 1, 1), (3, 2, 2)),
+                                      ((4, 3, 5), (4, 3, 5)), ((6, 5, 7), (3, 5, 4)), ((1, 6, 7), (1, 11, 13))])
+def test_trilinear_resize3d(dtype, src, size):
+    """F.interpolate(mode='trilinear') with align_corners unset, as PConvUNet3d(upsampling_mode='trilinear') calls it
+    (infill3d.py:217-220): dyadic and non-dyadic scales, the identity, a downsampling; the gather adjoint against autograd."""
+    n, c = 2, 8
+    x = rnd((n, c) + src, 6, dtype).requires_grad_(True)
+    ref = F.interpolate(x, size=size, mode="trilinear")
+    go = rnd(tuple(ref.shape), 7, dtype)
+    ref.backward(go)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = d3.from_folded(ops.TrilinearResize3dFn.apply(d3.to_folded(xd, pad_to(c, vec_of(dtype)), dtype), n, *size), n, c)
+    close(y.detach().cpu(), ref.detach(), 1e-6 if dtype == F32 else 8e-3, "y")
+    y.backward(go.to(DEV))
+    close(xd.grad.cpu(), x.grad, 1e-5 if dtype == F32 else 1e-2, "dx")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("rows_mask", [True, False])
+def test_pc_dropout3d(dtype, rows_mask):
+    """PCDropout3d.forward (infill3d.py:119-131) for an injected draw: the mask bit for bit, the input and its adjoint;
+    evaluation mode is the identity."""
+    n, c, d, h, w, p = 3, 16, 4, 3, 5, 0.25
+    g = torch.Generator().manual_seed(21)
+    x = rnd((n, c, d, h, w), 22, dtype).requires_grad_(True)
+    mk = (torch.rand((n, 1 if rows_mask else c, d, h, w), generator=g) > 0.4).float()
+    mask = mk.expand(n, c, d, h, w).contiguous()
+    keep = (torch.rand((n, c), generator=g) > p).float()
+    assert (keep == 0).any() and (keep == 1).any()
+    ref, ref_m = oi.pc_dropout3d(x, mask, keep, p)
+    go = rnd(tuple(ref.shape), 23, dtype)
+    ref.backward(go)
+    drop = i3.PCDropout3d(p).train()
+    drop.inject = [keep.clone()]
+    xd = x.detach().to(DEV).requires_grad_(True)
+    m_in = ops.RowsMask(mk.reshape(-1).to(DEV), c) if rows_mask else d3.to_folded(mask.to(DEV), c, dtype)
+    y, m_out = drop(d3.to_folded(xd, c, dtype), m_in, n, c)
+    assert torch.equal(d3.from_folded(m_out, n, c).cpu(), ref_m)
+    close(d3.from_folded(y, n, c).detach().cpu(), ref.detach(), 1e-6 if dtype == F32 else 8e-3, "y")
+    d3.from_folded(y, n, c).backward(go.to(DEV))
+    close(xd.grad.cpu(), x.grad, 1e-6 if dtype == F32 else 8e-3, "dx")
+    drop.eval()
+    h_in = d3.to_folded(xd.detach(), c, dtype)
+    y2, m2 = drop(h_in, m_in, n, c)
+    assert y2 is h_in and m2 is m_in
+    # without an injected draw: Bernoulli(1 - p) per (sample, channel); whole maps go or stay
+    drop.train()
+    _, m3 = drop(h_in, ops.RowsMask(torch.ones(n * d * h * w, device=DEV), c), n, c)
+    per_map = d3.from_folded(m3, n, c).flatten(2)
+    assert torch.equal(per_map.amax(2), per_map.amin(2)) and set(per_map.unique().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("tag", ["tri", "drop", "tridrop"])
+def test_unet3d_options_vs_reference_golden(golden_dir, dtype, tag):
+    """PConvUNet3d(upsampling_mode='trilinear' / dropout_p > 0) against the reference's modules; the dropout draws are the
+    ones recorded from the reference's nn.Dropout3d (tests/golden/infill3d_options_c2_18x10x14.npz)."""
+    z = np.load(os.path.join(golden_dir, "infill3d_options_c2_18x10x14.npz"))
+    m = json.loads(str(z["meta"]))
+    nk = int(z[tag + "::n_keeps"])
+    G = ig.Generator(layer_size=m["g_layers"], input_channels=m["cin"], output_channels=m["cout"], normalizer=nn.BatchNorm3d,
+                     upsampling_mode="nearest" if tag == "drop" else "trilinear", dropout_p=m["p_drop"] if nk else 0.0,
+                     compute_dtype=dtype)
+    G.load_state_dict(oi.fill_state(oi.unet3d_spec(m["cin"], m["cout"], m["g_layers"]), m["g_seed"]))
+    G.to(DEV).train()
+    if nk:
+        G.dropout.inject = [torch.from_numpy(z[f"{tag}::keep_{i}"]) for i in range(nk)]
+    x, gt, mask = oi.synthetic_infill(m["n"], m["cin"], m["d"], m["h"], m["w"], m["field_seed"])
+    out, out_mask = G(x.to(DEV), mask.to(DEV))
+    assert not (nk and G.dropout.inject), "every recorded draw must have been consumed"
+    assert np.array_equal(out_mask.cpu().numpy(), z[tag + "::out_mask"])
+    r = rms(out.detach().cpu(), z[tag + "::out"])
+    print(f"unet3d[{tag}] {dtype}: fwd rms-rel {r:.2e}")
+    if dtype == F32:
+        close(out.detach().cpu(), torch.from_numpy(z[tag + "::out"]), 5e-5, "out")
+    else:
+        assert r <= 1e-1
+    co = m["cout"]
+    ld = ig.InpaintingLoss("smooth-l1")(x[:, :co].to(DEV), out, gt[:, :co].to(DEV), mask[:, :co].to(DEV))
+    (6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]).backward()
+    torch.cuda.synchronize()
+    named = dict(G.named_parameters())
+    pre = tag + "::grad::"
+    worst = max(rms(named[k[len(pre):]].grad.cpu(), z[k]) for k in z.files if k.startswith(pre))
+    print(f"unet3d[{tag}] {dtype}: selected gradients worst rms-rel {worst:.2e}")
+    assert worst <= (1e-2 if dtype == F32 else 3e-1)     # bounds of test_unet3d_vs_reference_golden
+
+
 @pytest.mark.parametrize("kind", ["l1", "smooth-l1", "l2"])
 def test_inpainting_loss(kind):
     n, c, d, h, w = 2, 1, 6, 7, 5
@@ -322,15 +411,16 @@ def test_infill_trainer_whole_step_graph_matches_eager(monkeypatch):
             assert abs(a[4][k] - b[4][k]) <= 2e-5 * abs(a[4][k]) + 1e-6, (i, k, a[4][k], b[4][k])
 
 
+@pytest.mark.parametrize("fixture", ["infill2d_c2_40x56.npz", "infill2d_bilinear_c2_22x26.npz"])
 @pytest.mark.parametrize("dtype", [F32, BF16])
-def test_unet2d_vs_reference_golden(golden_dir, dtype):
+def test_unet2d_vs_reference_golden(golden_dir, dtype, fixture):
     """2-D PConvUNet / PartialConv2d (SURVEY 8(f)-4 "2-D shapes"): the planar mask window, masks bit-exact, the
     inpainting loss on 4-D tensors (total variation along W and H)."""
     from bias_gan_amd.architecture.gpsro import infill as i2
-    z = np.load(os.path.join(golden_dir, "infill2d_c2_40x56.npz"))
+    z = np.load(os.path.join(golden_dir, fixture))
     m = json.loads(str(z["meta"]))
     G = i2.PConvUNet(layer_size=m["layers"], input_channels=m["c"], output_channels=m["c"], normalizer=nn.BatchNorm2d,
-                     compute_dtype=dtype)
+                     upsampling_mode=m.get("mode", "nearest"), compute_dtype=dtype)
     G.load_state_dict(oi.fill_state(oi.unet2d_spec(m["c"], m["c"], m["layers"]), m["seed"]))
     G.to(DEV).train()
     gen = torch.Generator().manual_seed(m["field_seed"])

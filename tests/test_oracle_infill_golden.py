@@ -61,6 +61,41 @@ def test_unet3d(z):
             assert np.array_equal(mm[:, :1].numpy(), z[f"g::enc_mask_{i}"]), i
 
 
+@pytest.mark.parametrize("tag", ["tri", "drop", "tridrop"])
+def test_unet3d_options(golden_dir, tag):
+    """upsampling_mode='trilinear' and PCDropout3d (infill3d.py:115-135, :217-222): the oracle against the reference's
+    modules, the dropout draws being the ones recorded from the reference's nn.Dropout3d (make_golden.py infill3d_options)."""
+    z = np.load(os.path.join(golden_dir, "infill3d_options_c2_18x10x14.npz"))
+    m = json.loads(str(z["meta"]))
+    spec = oi.unet3d_spec(m["cin"], m["cout"], m["g_layers"])
+    P = oi.fill_state(spec, m["g_seed"])
+    keys = oi.trainable_keys(spec)
+    for k in keys:
+        P[k].requires_grad_(True)
+    x, gt, mask = oi.synthetic_infill(m["n"], m["cin"], m["d"], m["h"], m["w"], m["field_seed"])
+    nk = int(z[tag + "::n_keeps"])
+    assert nk == (0 if tag == "tri" else 2 * m["g_layers"])
+    keeps = [torch.from_numpy(z[f"{tag}::keep_{i}"]) for i in range(nk)]
+    if nk:
+        assert any((k_ == 0).any() for k_ in keeps), "the recorded draw drops nothing: the case would not test dropout"
+    out, out_mask = oi.unet3d(P, x, mask, m["g_layers"], oi.NormCtx("batch", True), upsampling_mode="nearest" if tag == "drop" else "trilinear",
+                              dropout_p=m["p_drop"] if nk else 0.0, keeps=keeps)
+    _close(out.detach().numpy(), z[tag + "::out"], what="out")
+    assert np.array_equal(out_mask.numpy(), z[tag + "::out_mask"])
+    co = m["cout"]
+    ld = oi.inpainting_loss(x[:, :co], out, gt[:, :co], mask[:, :co])
+    (6.0 * ld["hole"] + 1.0 * ld["valid"] + 0.1 * ld["tv"]).backward()
+    ref = dict(zip([str(k) for k in z[tag + "::grad_keys"]], z[tag + "::grad_cs"]))
+    assert list(ref.keys()) == keys
+    for k in keys:
+        got = _cs(P[k].grad)
+        assert abs(got[2] - ref[k][2]) <= 1e-3 * ref[k][2] + 1e-12, (k, got, ref[k])
+    pre = tag + "::grad::"
+    for k in z.files:
+        if k.startswith(pre):
+            _close(P[k[len(pre):]].grad.numpy(), z[k], rtol=5e-4, what=k)
+
+
 def test_disc3d(z):
     m = json.loads(str(z["meta"]))
     spec = oi.disc3d_spec(m["cout"], m["d_layers"])
@@ -134,10 +169,11 @@ def _fields2d(m):
     return gt * mask, gt, mask
 
 
-def test_unet2d(golden_dir):
+@pytest.mark.parametrize("fixture", ["infill2d_c2_40x56.npz", "infill2d_bilinear_c2_22x26.npz"])
+def test_unet2d(golden_dir, fixture):
     """The 2-D PConvUNet (infill.py) and PartialConv2d against vectors from the reference's modules
-    (tests/golden/infill2d_c2_40x56.npz; make_golden.py infill2d)."""
-    z = np.load(os.path.join(golden_dir, "infill2d_c2_40x56.npz"))
+    (make_golden.py infill2d / infill2d_bilinear: upsampling_mode 'nearest' and 'bilinear')."""
+    z = np.load(os.path.join(golden_dir, fixture))
     m = json.loads(str(z["meta"]))
     spec = oi.unet2d_spec(m["c"], m["c"], m["layers"])
     P = oi.fill_state(spec, m["seed"])
@@ -145,7 +181,7 @@ def test_unet2d(golden_dir):
     for k in keys:
         P[k].requires_grad_(True)
     x, gt, mask = _fields2d(m)
-    out, out_mask = oi.unet2d(P, x, mask, m["layers"], oi.NormCtx("batch", True))
+    out, out_mask = oi.unet2d(P, x, mask, m["layers"], oi.NormCtx("batch", True), upsampling_mode=m.get("mode", "nearest"))
     _close(out.detach().numpy(), z["out"], what="out")
     assert np.array_equal(out_mask.numpy(), z["out_mask"])
     ld = oi.inpainting_loss(x, out, gt, mask, "l1")
