@@ -103,14 +103,6 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
 
     float wf[9][4], dwa[9][4], a1[4], a2[4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        s16x4 v = {0, 0, 0, 0};
-        if (c_ok) v = *reinterpret_cast<const s16x4*>(P.w + (long long)t * P.C + c0);
-        unpack4(v, wf[t]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dwa[t][e] = 0.f;
-    }
-#pragma unroll
     for (int e = 0; e < 4; ++e) a1[e] = a2[e] = 0.f;
     float sc[4], sh[4], rs[4], mo[4];
     int cur_g = -1;
@@ -195,6 +187,15 @@ __global__ __launch_bounds__(FB_THREADS) void dw_bwd_fused_kernel(DwFusedParams 
         for (int j = 0; j < SLOTS_A; ++j) dma_a(j);
 #pragma unroll
         for (int j = 0; j < SLOTS_Z; ++j) dma_z(j);
+    }
+    // the filter taps AFTER the first tile's pieces are on their way (their round trip would otherwise precede the DMA's)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        s16x4 v = {0, 0, 0, 0};
+        if (c_ok) v = *reinterpret_cast<const s16x4*>(P.w + (long long)t * P.C + c0);
+        unpack4(v, wf[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dwa[t][e] = 0.f;
     }
     // per-thread LDS bases inside a buffer (immediates do the rest)
     const int lds_tap = ((pr + 2 * D) * FB_PITCH + pc + 2 * D) * 128 + it * 8;
@@ -389,14 +390,6 @@ __global__ __launch_bounds__(FB_THREADS) void dw_fork_bwd_kernel(DwForkParams P)
 
     float wf[9][4], dwa[9][4], a1[4], a2[4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        s16x4 v = {0, 0, 0, 0};
-        if (c_ok) v = *reinterpret_cast<const s16x4*>(P.w + (long long)t * P.C + c0);
-        unpack4(v, wf[t]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dwa[t][e] = 0.f;
-    }
-#pragma unroll
     for (int e = 0; e < 4; ++e) a1[e] = a2[e] = 0.f;
     float rs[4], mo[4];
     int cur_g = -1;
@@ -482,6 +475,15 @@ __global__ __launch_bounds__(FB_THREADS) void dw_fork_bwd_kernel(DwForkParams P)
         dma_begin(tile, buf0);
 #pragma unroll
         for (int s_ = 0; s_ < G::SLOTS; ++s_) dma_slot(s_);
+    }
+    // the filter taps AFTER the first tile's pieces are on their way (their round trip would otherwise precede the DMA's)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        s16x4 v = {0, 0, 0, 0};
+        if (c_ok) v = *reinterpret_cast<const s16x4*>(P.w + (long long)t * P.C + c0);
+        unpack4(v, wf[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dwa[t][e] = 0.f;
     }
     const int lds_tap = ((pr + 2) * FB_PITCH + pc + 2) * 128 + it * 8;
     const int lds_p = G::DPIX * 128 + (pr * FB_TW + pc) * 128 + it * 8;

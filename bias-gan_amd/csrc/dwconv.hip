@@ -327,6 +327,63 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     const unsigned idx = xblk * 256u + threadIdx.x;
     const int n = band / P.bands, b = band - n * P.bands;
     float* ptab = reinterpret_cast<float*>(dw_smem + RING_LDS);  // [2][C] scale, shift (PRE with pre_sum)
+    // Order of the prologue: the ring's first rows are requested BEFORE the BatchNorm coefficients are formed.  The
+    // coefficient table needs a round trip of its own (the producer's fp64 sums) and the DMA does not depend on it; issued
+    // one after the other the two latencies added up -- 11.1 us against 6.6 for the same launch without the table on the
+    // 16 x 16 maps of the 256 x 256 configuration (rocprofv3 kernel trace).  Threads beyond the tile's items request
+    // nothing (out-of-range offsets) and leave after the table's barrier.
+    const bool active = idx < (unsigned)P.items;
+    const unsigned wq = idx / cv;
+    const int c = (int)(idx - wq * cv) * VEC;
+    const int D = P.dil;
+    const int pc = (int)wq / P.wgroups, gi = (int)wq - pc * P.wgroups;  // column phase, group inside it
+    const int wo0 = pc + gi * TW * D;
+    const int pr = b / P.bands_per_phase, bi = b - pr * P.bands_per_phase;  // row phase, band inside it
+    const int ho0 = pr + bi * P.rb * D;
+    const int ho1 = min(ho0 + P.rb * D, P.Ho);
+    const unsigned row_bytes = (unsigned)P.W * P.ldx * sizeof(T);
+    const unsigned orow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
+    const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * row_bytes;
+    char* yn = reinterpret_cast<char*>(P.y) + (long long)n * P.Ho * orow_bytes;
+    int voff[NCOL], goff[TW], aoff[TW];  // negative (left of the image) -> huge unsigned -> out of range -> 0 / dropped
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) voff[j] = active ? ((wo0 + (j - 1) * D) * P.ldx + c) * (int)sizeof(T) : (int)0x80000000;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        goff[t] = ((wo0 + t * D) * P.ldy + c) * (int)sizeof(T);
+        aoff[t] = ADD ? (active ? ((wo0 + t * D) * P.ldadd + c) * (int)sizeof(T) : (int)0x80000000) : 0;
+    }
+    const unsigned arow_bytes = ADD ? (unsigned)P.Wo * P.ldadd * sizeof(T) : 0u;
+    const char* an = ADD ? reinterpret_cast<const char*>(P.add) + (long long)n * P.Ho * arow_bytes : nullptr;
+    const int lane = threadIdx.x & 63;
+    char* wb = dw_smem + (threadIdx.x >> 6) * (PF * NC * 1024);
+    const int nout = (ho1 - ho0 + D - 1) / D;  // output rows of this band (on its row phase)
+    const int Q = nout + 2;                    // input rows q = 0 .. Q-1 at image row ho0 + (q-1) D
+    auto issue_row = [&](int q, int slot) {
+        const int ih = ho0 + (q - 1) * D;
+        const bool ok = (unsigned)ih < (unsigned)P.H;  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(xn + (long long)(ok ? ih : 0) * row_bytes), 0, ok ? row_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) dw_dma16(rs, wb + (slot * NC + j) * 1024, voff[j]);
+        if (ADD) {   // the addend of output row ho0 + (q-2) D, the row this slot completes
+            const int oh = ho0 + (q - 2) * D;
+            const bool aok = q >= 2 && oh < ho1;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(an + (long long)(aok ? oh : 0) * arow_bytes), 0, aok ? arow_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) dw_dma16(ra, wb + (slot * NC + NCOL + t) * 1024, aoff[t]);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+        if (q < Q) issue_row(q, q);
+    Chunk<T> wv[9];
+    if (active) {
+        const T* w = reinterpret_cast<const T*>(P.w) + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t].load(w + (FLIP ? 8 - t : t) * P.C);
+    }
     if (PRE && P.pre_sum) {   // block-uniform
         const int g = n / P.pre_ipg;
         const bool publish = b == 0 && xblk == 0 && n == g * P.pre_ipg;  // first block of the group's first image
@@ -367,35 +424,7 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
         }
         __syncthreads();
     }
-    if (idx >= (unsigned)P.items) return;
-    const unsigned wq = idx / cv;
-    const int c = (int)(idx - wq * cv) * VEC;
-    const int D = P.dil;
-    const int pc = (int)wq / P.wgroups, gi = (int)wq - pc * P.wgroups;  // column phase, group inside it
-    const int wo0 = pc + gi * TW * D;
-    const int pr = b / P.bands_per_phase, bi = b - pr * P.bands_per_phase;  // row phase, band inside it
-    const int ho0 = pr + bi * P.rb * D;
-    const int ho1 = min(ho0 + P.rb * D, P.Ho);
-    const unsigned row_bytes = (unsigned)P.W * P.ldx * sizeof(T);
-    const unsigned orow_bytes = (unsigned)P.Wo * P.ldy * sizeof(T);
-    const char* xn = reinterpret_cast<const char*>(P.x) + (long long)n * P.H * row_bytes;
-    char* yn = reinterpret_cast<char*>(P.y) + (long long)n * P.Ho * orow_bytes;
-    int voff[NCOL], goff[TW], aoff[TW];  // negative (left of the image) -> huge unsigned -> out of range -> 0 / dropped
-#pragma unroll
-    for (int j = 0; j < NCOL; ++j) voff[j] = ((wo0 + (j - 1) * D) * P.ldx + c) * (int)sizeof(T);
-#pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        goff[t] = ((wo0 + t * D) * P.ldy + c) * (int)sizeof(T);
-        aoff[t] = ADD ? ((wo0 + t * D) * P.ldadd + c) * (int)sizeof(T) : 0;
-    }
-    const unsigned arow_bytes = ADD ? (unsigned)P.Wo * P.ldadd * sizeof(T) : 0u;
-    const char* an = ADD ? reinterpret_cast<const char*>(P.add) + (long long)n * P.Ho * arow_bytes : nullptr;
-    Chunk<T> wv[9];
-    {
-        const T* w = reinterpret_cast<const T*>(P.w) + c;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wv[t].load(w + (FLIP ? 8 - t : t) * P.C);
-    }
+    if (!active) return;
     float psc[VEC], psh[VEC];
     bool cok[NCOL];
     const float pslope = act_max_slope(P.pre_act);
@@ -416,29 +445,6 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(wo0 + (j - 1) * D) < (unsigned)P.W;
     }
-    const int lane = threadIdx.x & 63;
-    char* wb = dw_smem + (threadIdx.x >> 6) * (PF * NC * 1024);
-    const int nout = (ho1 - ho0 + D - 1) / D;  // output rows of this band (on its row phase)
-    const int Q = nout + 2;                    // input rows q = 0 .. Q-1 at image row ho0 + (q-1) D
-    auto issue_row = [&](int q, int slot) {
-        const int ih = ho0 + (q - 1) * D;
-        const bool ok = (unsigned)ih < (unsigned)P.H;  // wave-uniform
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(xn + (long long)(ok ? ih : 0) * row_bytes), 0, ok ? row_bytes : 0u, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NCOL; ++j) dw_dma16(rs, wb + (slot * NC + j) * 1024, voff[j]);
-        if (ADD) {   // the addend of output row ho0 + (q-2) D, the row this slot completes
-            const int oh = ho0 + (q - 2) * D;
-            const bool aok = q >= 2 && oh < ho1;
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(an + (long long)(aok ? oh : 0) * arow_bytes), 0, aok ? arow_bytes : 0u, 0x00020000);
-#pragma unroll
-            for (int t = 0; t < TW; ++t) dw_dma16(ra, wb + (slot * NC + NCOL + t) * 1024, aoff[t]);
-        }
-    };
-#pragma unroll
-    for (int q = 0; q < PF; ++q)
-        if (q < Q) issue_row(q, q);
     // Scatter form: the new input row is unpacked ONCE and added into the three output rows it contributes to (taps
     // 0-2 of output row q, 3-5 of row q-1, 6-8 of row q-2, which is complete afterwards and stored).  The gather form --
     // three packed rows kept, all three unpacked again for every output row -- spent 144 of its 304 VALU instructions

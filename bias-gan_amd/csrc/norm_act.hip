@@ -436,6 +436,24 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     long long r1 = r0 + P.rows_per_block;
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
+    // The first batch of rows is requested BEFORE the coefficient table is formed: the table costs a round trip of its own
+    // (the producer's fp64 sums) on which the loads do not depend, and on small maps -- where a launch is a few microseconds
+    // of latency, not bandwidth -- the two round trips otherwise add up.
+    const bool c_ok = c < P.C;
+    const T* x = reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c;
+    const T* res = RES ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
+    const long long sx = (long long)ty * P.ldx, sr = (long long)ty * P.ldres, sy = (long long)ty * P.ldy;
+    long long r = r0 + ly;
+    const long long step = EW_U * (long long)ty;
+    Chunk<T> vx[EW_U], vr[EW_U];
+    bool have = c_ok && r + step - ty < r1;
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            vx[u].load(x + u * sx);
+            if (RES) vr[u].load(res + u * sr);
+        }
+    }
     // Per-channel affine: the block derives it ONCE per channel, lanes along channels (coalesced table reads), and
     // hands it to the row lanes through LDS.  When every thread read its own 8 channels straight from the tables, each
     // wave-level load touched 32-64 cache lines for 4-8 useful bytes per lane: rocprofv3 counted 8x the L1 accesses of
@@ -494,17 +512,14 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
         }
     }
     __syncthreads();
-    if (c >= P.C) return;
+    if (!c_ok) return;
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         sc[e] = s_sc[e * P.tx + lx];
         sh[e] = s_sh[e * P.tx + lx];
     }
-    const T* x = reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c;
-    const T* res = RES ? reinterpret_cast<const T*>(P.res) + row0 * P.ldres + c : nullptr;
     T* y = reinterpret_cast<T*>(P.y) + row0 * P.ldy + c;
-    const long long sx = (long long)ty * P.ldx, sr = (long long)ty * P.ldres, sy = (long long)ty * P.ldy;
     // LeakyReLU / ReLU / identity as max(z, slope*z) with slope 0.2 / 0 / 1: the same values as the branch
     // (z >= 0 ? z : slope*z) for every slope in [0, 1], with no per-element selects on run-time flags.  These kernels
     // are HBM-bound only while the VALU work per 16-byte chunk stays small: with the act / residual flags tested per
@@ -522,17 +537,6 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(EwParams P) {
     };
     // EW_U rows per thread are in flight before the first is used, and the next batch is requested before the current
     // one is computed and stored (the one-row "#pragma unroll 4" loop compiled to load -> s_waitcnt vmcnt(0) -> store).
-    long long r = r0 + ly;
-    const long long step = EW_U * (long long)ty;
-    Chunk<T> vx[EW_U], vr[EW_U];
-    bool have = r + step - ty < r1;
-    if (have) {
-#pragma unroll
-        for (int u = 0; u < EW_U; ++u) {
-            vx[u].load(x + u * sx);
-            if (RES) vr[u].load(res + u * sr);
-        }
-    }
     while (have) {
         Chunk<T> cx[EW_U], cr[EW_U];
 #pragma unroll
@@ -605,6 +609,26 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
     if (r1 > P.rows_per_group) r1 = P.rows_per_group;
     const long long row0 = (long long)g * P.rows_per_group + r0 + ly;
     constexpr bool useB = USEB;
+    // first batch of rows requested before the coefficient table (see norm_act_fwd_kernel)
+    const bool c_ok = c < P.C;
+    constexpr bool LDX = USEB || SIGN == 2;
+    const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;
+    const T* y = SIGN == 1 ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
+    const T* x = LDX ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
+    const long long s_dy = (long long)ty * P.lddy, s_y = (long long)ty * P.ldy, s_x = (long long)ty * P.ldx;
+    auto load = [&](Chunk<T>* vg, Chunk<T>* vy, Chunk<T>* vx) {
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            vg[u].load(dy + u * s_dy);
+            if (SIGN == 1) vy[u].load(y + u * s_y);
+            if (LDX) vx[u].load(x + u * s_x);
+        }
+    };
+    long long r = r0 + ly;
+    const long long step = EW_U * (long long)ty;
+    Chunk<T> vg[EW_U], vy[EW_U], vx[EW_U];
+    bool have = c_ok && r + step - ty < r1;
+    if (have) load(vg, vy, vx);
     // per-channel coefficients once per block, lanes along channels, handed over through LDS (see norm_act_fwd_kernel)
     extern __shared__ float ew_tab[];
     const int row_w = P.tx * VEC, nthr = P.tx * ty;
@@ -649,7 +673,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
         }
     }
     __syncthreads();
-    if (c >= P.C) return;
+    if (!c_ok) return;
     float ca[VEC], cb[VEC], cc[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -659,13 +683,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
         sc[e] = ew_tab[3 * row_w + e * P.tx + lx];
         sh[e] = ew_tab[4 * row_w + e * P.tx + lx];
     }
-    constexpr bool LDX = USEB || SIGN == 2;
-    const T* dy = reinterpret_cast<const T*>(P.dy) + row0 * P.lddy + c;
-    const T* y = SIGN == 1 ? reinterpret_cast<const T*>(P.y) + row0 * P.ldy + c : nullptr;
-    const T* x = LDX ? reinterpret_cast<const T*>(P.x) + row0 * P.ldx + c : nullptr;
     T* dx = P.dx ? reinterpret_cast<T*>(P.dx) + row0 * P.lddx + c : nullptr;
     T* dres = DRES ? reinterpret_cast<T*>(P.dres) + row0 * P.lddres + c : nullptr;
-    const long long s_dy = (long long)ty * P.lddy, s_y = (long long)ty * P.ldy, s_x = (long long)ty * P.ldx;
     const long long s_dx = (long long)ty * P.lddx, s_dr = (long long)ty * P.lddres;
     const float slope = act_slope(P.act);
     const float q_scale = Q8 ? ldexpf(1.f, *P.q_exp) : 0.f;
@@ -716,20 +735,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
             }
         }
     };
-    auto load = [&](Chunk<T>* vg, Chunk<T>* vy, Chunk<T>* vx) {
-#pragma unroll
-        for (int u = 0; u < EW_U; ++u) {
-            vg[u].load(dy + u * s_dy);
-            if (SIGN == 1) vy[u].load(y + u * s_y);
-            if (LDX) vx[u].load(x + u * s_x);
-        }
-    };
     // software-pipelined batches of EW_U rows (see norm_act_fwd_kernel)
-    long long r = r0 + ly;
-    const long long step = EW_U * (long long)ty;
-    Chunk<T> vg[EW_U], vy[EW_U], vx[EW_U];
-    bool have = r + step - ty < r1;
-    if (have) load(vg, vy, vx);
     while (have) {
         Chunk<T> cg[EW_U], cy[EW_U], cx[EW_U];
 #pragma unroll
