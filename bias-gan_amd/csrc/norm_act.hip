@@ -1009,9 +1009,11 @@ extern "C" int bg_norm_act_fwd_stats(int32_t dtype, const void* x, int32_t ldx, 
         BG_CHECK_ARG(aligned16(res), "bg_norm_act_fwd_stats: unaligned res");
         CHECK_LD(ldres, "bg_norm_act_fwd_stats");
     }
-    // fewer, longer-running threads than the plain apply kernel: each thread first derives its
-    // channels' affine from the sums, which must be amortised over the rows it then walks
-    static const int k_rows = env_int("BGAMD_EWS_ROWS", 16), k_blocks = env_int("BGAMD_EWS_BLOCKS", 1024);  // tuning knobs
+    // fewer, longer-running blocks than the plain apply kernel (1 024 against 8 192): each block first derives its channels'
+    // affine from the sums, which must be amortised over the rows it then walks.  The floor of rows per thread is 4, one
+    // batch of loads: with 16 the 16 x 16 maps of the 256 x 256 configuration ran as 64 blocks of four dependent batches
+    // (256 x 256 step 22.53 -> 22.12 ms, 1152 x 768 unchanged; scripts/gpu_ews.sh)
+    static const int k_rows = env_int("BGAMD_EWS_ROWS", 4), k_blocks = env_int("BGAMD_EWS_BLOCKS", 1024);  // tuning knobs
     const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks, common_ld({ldx, ldy, res ? ldres : 0}));
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_fwd_stats: too many groups");
     EwParams P{x, ldx, nullptr, nullptr, res, ldres, y, ldy, C, rows / groups, t.rows_per_block, act, t.tx, t.ty,
@@ -1082,7 +1084,7 @@ int bwd_apply_stats_impl(int32_t dtype, const void* dy, int32_t lddy, const void
         BG_CHECK_ARG(aligned16(dres), "bg_norm_act_bwd_apply_stats: unaligned dres");
         CHECK_LD(lddres, "bg_norm_act_bwd_apply_stats");
     }
-    static const int k_rows = env_int("BGAMD_EWS_ROWS", 16), k_blocks = env_int("BGAMD_EWB_BLOCKS", 256);  // tuning knobs
+    static const int k_rows = env_int("BGAMD_EWS_ROWS", 4), k_blocks = env_int("BGAMD_EWB_BLOCKS", 256);  // tuning knobs
     const Tiling t = make_tiling(dtype, C, rows / groups, groups, k_rows, k_blocks,
                                  common_ld({lddy, y ? ldy : 0, ldx, dx ? lddx : 0, dres ? lddres : 0}));
     BG_CHECK_ARG(groups <= 65535, "bg_norm_act_bwd_apply_stats: too many groups");
