@@ -99,15 +99,22 @@ def _e32(*shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-# ------------------------------------------------------- weight gradients on a second stream
+# ------------------------------------------------------- weight gradients on a second stream (opt-in)
 # In a backward pass the data-gradient chain is the critical path; the weight gradients hang off it
-# and nothing downstream reads them before the optimiser.  They are issued on a second HIP stream so
-# that their workgroups fill the tails and ramps of the (short) kernels of the chain.  The stream is
+# and nothing downstream reads them before the optimiser.  They CAN be issued on a second HIP stream so
+# that their workgroups fill the tails and ramps of the (short) kernels of the chain; the stream is
 # joined back into the caller's stream when the autograd engine finishes the pass (queue_callback),
-# so .grad is ordered like any other result of backward().  BGAMD_NO_WGRAD_STREAM=1 disables.
+# so .grad is ordered like any other result of backward().  Off by default since round 4 (BGAMD_WGRAD_STREAM=1
+# enables): with most weight gradients deferred to the grouped launches at the end of the pass there is little
+# left to overlap, and what is left competes with the chain's own kernels for the chip -- same-box A/B
+# (scripts/gpu_wgs.sh): 1152 x 768 114.2 -> 112.7 ms, wgan-gp 135.6 -> 133.2, 2304 x 1536 x 32 232.7 -> 229.2,
+# 256 x 256 22.0 -> 21.7 without it.
 _WG_STREAMS = {}
 _WG_PENDING = {}     # device -> graph task id of the backward pass whose callback is registered
-_WG_ENABLED = not _os.environ.get("BGAMD_NO_WGRAD_STREAM")
+_WG_ENABLED = _os.environ.get("BGAMD_WGRAD_STREAM", "0") != "0" and not _os.environ.get("BGAMD_NO_WGRAD_STREAM")
+# ... and then only for layers whose activation has at least this many elements: below it (the 16 x 16 and 32 x 32 maps
+# of the 256 x 256 configuration) a launch is a few microseconds of latency and the fork / join costs more than it hides
+_WG_MIN_ELEMS = int(_os.environ.get("BGAMD_WGRAD_STREAM_MIN", str(8 << 20)))
 
 
 def _wg_register(key):
@@ -125,7 +132,8 @@ def _wg_register(key):
 def wgrad_call(dev, tensors, name, *args):
     """Launch a weight-gradient entry point on the second stream (after everything enqueued so far on the
     caller's stream); `tensors` are the operands whose memory must outlive that launch."""
-    if not _WG_ENABLED or L.PROFILE is not None or torch._C._current_graph_task_id() < 0:
+    if (not _WG_ENABLED or L.PROFILE is not None or torch._C._current_graph_task_id() < 0
+            or max(t.numel() for t in tensors) < _WG_MIN_ELEMS):
         L.call(name, *args)   # the profile step times ONE kernel per event pair; outside a backward pass nothing would join
         return
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -229,8 +237,8 @@ def wgrad_group_flush(key, only_sig=None):
     if not groups:
         return
     dev = torch.device("cuda", key)
-    use_side = _WG_ENABLED and L.PROFILE is None
-    if use_side:
+    any_side = _WG_ENABLED and L.PROFILE is None and any(sig[0] * max(sig[1], sig[2]) >= _WG_MIN_ELEMS for sig in groups)
+    if any_side:
         ent = _WG_STREAMS.get(key)
         if ent is None:
             side = L.side_stream(dev, "wgrad")
@@ -238,6 +246,7 @@ def wgrad_group_flush(key, only_sig=None):
         side, raw = ent
         side.wait_stream(torch.cuda.current_stream(dev))
     for (rows, cin, cout, ldx, ldy), jobs in groups.items():
+        use_side = any_side and rows * max(cin, cout) >= _WG_MIN_ELEMS
         if use_side:
             for x, g, _, _ in jobs:
                 x.record_stream(side)

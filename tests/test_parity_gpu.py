@@ -703,13 +703,13 @@ def test_step_schedules_agree(dtype):
         torch.manual_seed(3)
         labels = crit.draw_labels()
         x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 77))
-        old = ops._WG_ENABLED
-        ops._WG_ENABLED = not plain
+        old, old_min = ops._WG_ENABLED, ops._WG_MIN_ELEMS
+        ops._WG_ENABLED, ops._WG_MIN_ELEMS = not plain, 0     # every layer on the weight-gradient stream, however small
         try:
             d_loss, g_loss = tr.step(x, y, labels=labels)
             torch.cuda.synchronize()
         finally:
-            ops._WG_ENABLED = old
+            ops._WG_ENABLED, ops._WG_MIN_ELEMS = old, old_min
         sd = D.state_dict()
         return (float(d_loss), float(g_loss), G.arena().master.double().clone(), D.arena().master.double().clone(),
                 sd["xception_features.bn1.running_mean"].clone(), sd["xception_features.bn1.running_var"].clone(),
