@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("BGAMD_LIB") or os.path.join(_HERE, "libbgamd.so")   #
 
 BF16, F32, FP8 = 0, 1, 2
 FP8_E4M3, FP8_E5M2 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -142,6 +142,10 @@ _SIGS = {
                      c_f32, c_vp],
     "bg_set_floats": [c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp],
     "bg_adam_step_dev": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, C.c_double, C.c_double, c_f32, c_f32, c_i32, c_vp],
+    "bg_sumsq_f32": [c_vp, c_i64, c_f32, c_vp, c_vp],
+    "bg_lamb_stage1": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, C.c_double, C.c_double, c_i32, c_f32, c_f32, c_i32, c_f32, c_f32, c_f32,
+                       c_vp, c_vp, c_vp],
+    "bg_lamb_stage2": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp],
     "bg_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
 }
 EXPORTS = sorted(list(_SIGS) + list(_HOST_SIGS) + ["bg_last_error", "bg_conv_weight_kpad", "bg_conv_set_variant"])

@@ -209,6 +209,77 @@ class FusedAdam(optim.Optimizer):
                 self._mom[id(a)] = (a, sd[f"exp_avg_{i}"].to(a.device).clone(), sd[f"exp_avg_sq_{i}"].to(a.device).clone())
 
 
+class FusedLAMB(FusedAdam):
+    """apex.optimizers.FusedLAMB as the reference constructs it (parsing_helpers.py:13-14: lr, eps, weight_decay; apex's
+    other defaults: betas (0.9, 0.999), bias_correction, adam_w_mode, grad_averaging, max_grad_norm 1.0, no nvlamb) over the
+    flat parameter arena -- bg_sumsq_f32 (global gradient norm), bg_lamb_stage1, bg_lamb_stage2; a "tensor" of the trust
+    ratio is a parameter's arena slot.  apex is not part of the reference tree: the arithmetic follows its published
+    two-stage kernel (see include/bgamd.h); moments, checkpoints and the DDP hand-over are FusedAdam's.  Steps run eagerly
+    (the trainers capture FusedAdam steps only)."""
+
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, adam_w_mode=True,
+                 grad_averaging=True, max_grad_norm=1.0, use_nvlamb=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=adam_w_mode)
+        for g in self.param_groups:
+            g.update(bias_correction=bool(bias_correction), grad_averaging=bool(grad_averaging), max_grad_norm=float(max_grad_norm),
+                     use_nvlamb=bool(use_nvlamb))
+        self._seg = {}     # id(arena) -> (arena, device int64 offsets [nseg + 1] of the slots of this optimiser, scratch)
+
+    def _segments(self, a, slots):
+        ent = self._seg.get(id(a))
+        if ent is None or ent[0] is not a or ent[1].device != a.master.device:
+            segs = [(s_.off, s_.off + s_.numel) for s_ in sorted(slots, key=lambda s_: s_.off)]
+            # the kernels take consecutive [seg[t], seg[t+1]) ranges: the alignment gaps between slots become filler tensors
+            # (arena padding: p = g = m = v = 0 there, so update 0 and norms 0)
+            cuts = []
+            pos = segs[0][0]
+            for lo, hi in segs:
+                if lo > pos:
+                    cuts.append(pos)
+                cuts.append(lo)
+                pos = hi
+            cuts.append(pos)
+            seg = torch.tensor(cuts, dtype=torch.int64, device=a.master.device)
+            ent = self._seg[id(a)] = (a, seg, torch.zeros(2 * (len(cuts) - 1) + 2, dtype=torch.float32, device=a.master.device),
+                                      torch.zeros(1, dtype=torch.float64, device=a.master.device))
+        return ent[1], ent[2], ent[3]
+
+    def prepare_replay(self):
+        raise RuntimeError("FusedLAMB: steps are not captured into hipGraphs")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self.capturing:
+            raise RuntimeError("FusedLAMB: steps are not captured into hipGraphs")
+        self._t += 1
+        for a, g, slots in self._arenas():
+            b1, b2 = g["betas"]
+            bc1, bc2 = (1.0 - b1 ** self._t, 1.0 - b2 ** self._t) if g["bias_correction"] else (1.0, 1.0)
+            m, v = self._moments(a)
+            scale = 1.0
+            ddp = getattr(a, "ddp", None)
+            if ddp is not None:
+                ddp.finish()
+                scale = 1.0 / ddp.world_size
+            seg, norms, gsq = self._segments(a, slots)
+            nseg = seg.numel() - 1
+            norms.zero_()
+            gsq.zero_()
+            # the global norm runs over the gradients of THIS optimiser's parameters (apex: all param groups of the instance);
+            # gaps hold zeros, so a parameter list that covers the arena is one launch
+            spans = [(0, a.numel)] if len(slots) == len(a.slots) else [(s_.off, s_.numel) for s_ in slots]
+            for off, cnt in spans:
+                L.call("bg_sumsq_f32", a.grad.data_ptr() + 4 * off, cnt, scale, gsq.data_ptr())
+            pn, un = norms.data_ptr(), norms.data_ptr() + 4 * (nseg + 1)
+            L.call("bg_lamb_stage1", a.master.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr(), seg.data_ptr(), nseg,
+                   gsq.data_ptr(), float(g["max_grad_norm"]), float(b1), float(b2), int(g["grad_averaging"]), float(g["eps"]),
+                   float(g["weight_decay"]), int(bool(g["decoupled"])), bc1, bc2, scale, pn, un)
+            L.call("bg_lamb_stage2", a.master.data_ptr(), a.grad.data_ptr(), None if a.lp is None else a.lp.data_ptr(), seg.data_ptr(),
+                   nseg, pn, un, float(g["lr"]), float(g["weight_decay"]), int(g["use_nvlamb"]))
+            a.refresh_copies(cast=False)
+            a._synced_version = a.master._version
+
+
 def get_optimizer(parameters, optimizer_name, start_lr, adam_eps, weight_decay):
     if isinstance(parameters, torch.nn.Module):   # the reference script hands the module over (train_gan.py:155-156)
         parameters = parameters.parameters()
@@ -216,6 +287,8 @@ def get_optimizer(parameters, optimizer_name, start_lr, adam_eps, weight_decay):
         optimizer = FusedAdam(parameters, lr=start_lr, eps=adam_eps, weight_decay=weight_decay)
     elif optimizer_name == "AdamW":
         optimizer = FusedAdam(parameters, lr=start_lr, eps=adam_eps, weight_decay=weight_decay, decoupled=True)
+    elif optimizer_name == "LAMB":
+        optimizer = FusedLAMB(parameters, lr=start_lr, eps=adam_eps, weight_decay=weight_decay)
     else:
         raise NotImplementedError("Error, optimizer {} not supported".format(optimizer_name))
     optimizer.param_groups[0]["initial_lr"] = start_lr

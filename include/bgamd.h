@@ -55,7 +55,7 @@ extern "C" {
 #define BG_E_ARG (-1)    /* bad argument / shape the kernels do not support */
 #define BG_E_LAUNCH (-2) /* hipLaunch failed (message carries hipGetErrorString) */
 
-#define BG_ABI_VERSION 3
+#define BG_ABI_VERSION 4
 
 int bg_abi_version(void);
 const char* bg_last_error(void);
@@ -501,6 +501,24 @@ int bg_adam_step(float* p, const float* g, float* m, float* v, void* p_lp /* bf1
 int bg_set_floats(float* dst, int32_t n, float v0, float v1, float v2, float v3, void* stream);
 int bg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_lp, int64_t n, const float* hyper, double beta1,
                      double beta2, float eps, float weight_decay, int32_t decoupled, void* stream);
+/* LAMB as the reference selects it (utils/parsing_helpers.py:13-14: apex.optimizers.FusedLAMB(lr, eps, weight_decay), a
+ * dependency that is not in the reference tree -- NVIDIA apex as shipped in nvcr.io/nvidia/pytorch:20.12-py3, docker/Dockerfile:1;
+ * restated from its published two-stage form, csrc/multi_tensor_lamb.cu) over a flat arena cut into parameter tensors
+ * [seg[t], seg[t+1]) (nseg + 1 offsets in device memory):
+ *   bg_sumsq_f32:   *out += sum (scale * x[i])^2                              -- the global gradient norm (caller zeroes out)
+ *   bg_lamb_stage1: s = grad_scale * g / max(1, ||g|| / max_grad_norm); adam_w_mode 0: s += wd p;
+ *                   m = b1 m + b3 s (b3 = 1 - b1 with grad_averaging, else 1); v = b2 v + (1 - b2) s^2;
+ *                   u = (m / bc1) / (sqrt(v / bc2) + eps) (+ wd p in adam_w_mode 1), written over g;
+ *                   param_sumsq[t] += sum p^2, update_sumsq[t] += sum u^2       (caller zeroes both)
+ *   bg_lamb_stage2: p -= ratio_t * u, ratio_t = lr * ||p_t|| / ||u_t|| where (weight_decay != 0 or use_nvlamb) and both
+ *                   norms are non-zero, else lr; refreshes the bf16 copy p_lp (may be NULL). */
+int bg_sumsq_f32(const float* x, int64_t n, float scale, double* out, void* stream);
+int bg_lamb_stage1(const float* p, float* g, float* m, float* v, const int64_t* seg, int32_t nseg, const double* grad_sumsq,
+                   float max_grad_norm, double beta1, double beta2, int32_t grad_averaging, float eps, float weight_decay,
+                   int32_t adam_w_mode, float bias_corr1, float bias_corr2, float grad_scale, float* param_sumsq, float* update_sumsq,
+                   void* stream);
+int bg_lamb_stage2(float* p, const float* update, void* p_lp, const int64_t* seg, int32_t nseg, const float* param_sumsq,
+                   const float* update_sumsq, float lr, float weight_decay, int32_t use_nvlamb, void* stream);
 int bg_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------

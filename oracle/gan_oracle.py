@@ -567,6 +567,54 @@ class Adam:
             p.addcdiv_(self.m[k], denom, value=-self.lr / bc1)
 
 
+class Lamb:
+    """apex.optimizers.FusedLAMB as utils/parsing_helpers.py:13-14 constructs it (lr, eps, weight_decay; apex's other
+    defaults).  apex is a dependency that is NOT in the reference tree (NVIDIA apex of nvcr.io/nvidia/pytorch:20.12-py3,
+    docker/Dockerfile:1), so this restates its published algorithm -- apex/optimizers/fused_lamb.py (global gradient norm
+    over all parameters, one step count per group) and csrc/multi_tensor_lamb.cu (LAMBStage1Functor / LAMBStage2Functor):
+    PARITY UNPINNED against apex itself; pinned where it can be: without weight decay and below the clipping norm the step
+    IS torch.optim.Adam's (tests/test_oracle_golden.py::test_lamb_*)."""
+
+    def __init__(self, keys: List[str], lr=1e-3, eps=1e-6, weight_decay=0.01, betas=(0.9, 0.999), bias_correction=True,
+                 adam_w_mode=True, grad_averaging=True, max_grad_norm=1.0, use_nvlamb=False):
+        self.keys, self.lr, self.eps, self.wd, self.betas = keys, lr, eps, weight_decay, betas
+        self.bias_correction, self.adam_w_mode, self.grad_averaging = bias_correction, adam_w_mode, grad_averaging
+        self.max_grad_norm, self.use_nvlamb = max_grad_norm, use_nvlamb
+        self.t = 0
+        self.m: State = {}
+        self.v: State = {}
+
+    @torch.no_grad()
+    def step(self, P: State, grads: State):
+        self.t += 1
+        b1, b2 = self.betas
+        b3 = 1 - b1 if self.grad_averaging else 1.0
+        bc1, bc2 = (1 - b1 ** self.t, 1 - b2 ** self.t) if self.bias_correction else (1.0, 1.0)
+        keys = [k for k in self.keys if grads.get(k) is not None]
+        gnorm = math.sqrt(sum(float((grads[k].double() ** 2).sum()) for k in keys))
+        clip = gnorm / self.max_grad_norm if (self.max_grad_norm > 0 and gnorm > self.max_grad_norm) else 1.0
+        for k in keys:
+            p = P[k]
+            sg = grads[k] / clip
+            if not self.adam_w_mode:
+                sg = sg + self.wd * p
+            if k not in self.m:
+                self.m[k] = torch.zeros_like(p)
+                self.v[k] = torch.zeros_like(p)
+            self.m[k].mul_(b1).add_(sg, alpha=b3)
+            self.v[k].mul_(b2).addcmul_(sg, sg, value=1 - b2)
+            u = (self.m[k] / bc1) / ((self.v[k] / bc2).sqrt() + self.eps)
+            if self.adam_w_mode:
+                u = u + self.wd * p
+            ratio = self.lr
+            if self.use_nvlamb or self.wd != 0:
+                pn, un = float(p.double().norm()), float(u.double().norm())
+                if pn != 0.0 and un != 0.0:
+                    ratio = self.lr * pn / un
+            p.add_(u, alpha=-ratio)
+
+
+
 # ----------------------------------------------------------------------------
 # The training step (train_gan.py:244-298)
 # ----------------------------------------------------------------------------

@@ -100,8 +100,12 @@ def test_optimizer_factory_and_schedules():
     opt = ph.get_optimizer(p, "Adam", 1e-3, 1e-8, 1e-4)
     assert opt.param_groups[0]["initial_lr"] == 1e-3 and not opt.param_groups[0]["decoupled"]
     assert ph.get_optimizer(p, "AdamW", 1e-3, 1e-8, 1e-4).param_groups[0]["decoupled"]
+    lamb = ph.get_optimizer(p, "LAMB", 1e-3, 1e-8, 1e-4)     # apex FusedLAMB's defaults beside the three the reference passes
+    g0 = lamb.param_groups[0]
+    assert (type(lamb).__name__, g0["lr"], g0["eps"], g0["weight_decay"], g0["max_grad_norm"], g0["decoupled"], g0["grad_averaging"],
+            g0["use_nvlamb"]) == ("FusedLAMB", 1e-3, 1e-8, 1e-4, 1.0, True, True, False)
     with pytest.raises(NotImplementedError):
-        ph.get_optimizer(p, "LAMB", 1e-3, 1e-8, 1e-4)
+        ph.get_optimizer(p, "SGD", 1e-3, 1e-8, 1e-4)
     sch = ph.get_lr_schedule(1e-3, {"type": "multistep", "milestones": "2 4", "decay_rate": "0.1"}, opt)
     lrs = []
     for _ in range(5):

@@ -245,3 +245,50 @@ def test_c1_plumbing_three_iterations(golden_dir):
         assert abs(gl.item() - z["g_loss"][s]) <= 2e-5 * abs(z["g_loss"][s]), (s, gl.item(), z["g_loss"][s])
     _close(P["g.0.weight"].numpy(), z["final::g.0.weight"], rtol=1e-5)
     assert abs(_cs(P["dlin.weight"])[1] - z["final::dlin.weight_cs"][1]) <= 1e-5 * z["final::dlin.weight_cs"][1]
+
+
+def _lamb_fixture(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    P = {"a": torch.randn(5, 7, generator=g), "b": torch.randn(11, generator=g), "c": torch.randn(3, 2, 3, 3, generator=g)}
+    grads = [{k: 0.05 * torch.randn(v.shape, generator=g) for k, v in P.items()} for _ in range(4)]
+    return P, grads
+
+
+def test_lamb_is_adam_below_the_clipping_norm_without_decay():
+    """The part of the LAMB restatement (oracle.Lamb; apex is not in the reference tree) that CAN be pinned: with
+    weight_decay = 0 the trust ratio is off, and with ||g|| <= max_grad_norm nothing is clipped -- the step is then
+    torch.optim.Adam's, moments included."""
+    P, grads = _lamb_fixture()
+    Q = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = torch.optim.Adam(list(Q.values()), lr=1e-3, eps=1e-6)
+    lam = orc.Lamb(list(P), lr=1e-3, eps=1e-6, weight_decay=0.0)
+    for g in grads:
+        assert sum(float((x.double() ** 2).sum()) for x in g.values()) < 1.0
+        for k in Q:
+            Q[k].grad = g[k].clone()
+        ref.step()
+        lam.step(P, g)
+        for i, k in enumerate(P):
+            assert (P[k] - Q[k].detach()).abs().max().item() <= 2e-7
+            st = ref.state[Q[k]]
+            assert (lam.m[k] - st["exp_avg"]).abs().max().item() <= 1e-8 and (lam.v[k] - st["exp_avg_sq"]).abs().max().item() <= 1e-9
+
+
+def test_lamb_clips_by_the_global_norm_and_scales_by_the_trust_ratio():
+    """Gradients k times larger than the clipping norm give the step of gradients AT the norm (the global norm runs over all
+    tensors); with weight decay each tensor moves by lr * ||p|| / ||u|| * u with u = adam direction + wd * p."""
+    P, grads = _lamb_fixture(1)
+    g = grads[0]
+    gn = sum(float((x.double() ** 2).sum()) for x in g.values()) ** 0.5
+    at = {k: x / gn for k, x in g.items()}                 # global norm exactly 1 = max_grad_norm
+    big = {k: 7.5 * x for k, x in at.items()}
+    A, B = {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}
+    orc.Lamb(list(P), lr=1e-2, eps=1e-6, weight_decay=0.01).step(A, at)
+    orc.Lamb(list(P), lr=1e-2, eps=1e-6, weight_decay=0.01).step(B, big)
+    for k in P:
+        assert (A[k] - B[k]).abs().max().item() <= 1e-6
+        # first step: m / bc1 = s, v / bc2 = s^2 -> adam direction s / (|s| + eps)
+        s_ = at[k]
+        u = s_ / (s_.abs() + 1e-6) + 0.01 * P[k]
+        want = P[k] - 1e-2 * (P[k].norm() / u.norm()) * u
+        assert (A[k] - want).abs().max().item() <= 1e-6

@@ -175,6 +175,40 @@ def build_discriminator(c, h, w, seed, dtype, norm=nn.BatchNorm2d, kind="batch")
     return D.to(DEV), spec
 
 
+def test_fused_lamb_matches_the_oracle_restatement():
+    """utils/parsing_helpers.py:13-14 (optimizer 'LAMB' = apex FusedLAMB): bg_sumsq_f32 + bg_lamb_stage1 + bg_lamb_stage2 over
+    the generator's arena against oracle.Lamb fed the SAME gradients, three steps: the first with the global norm above
+    max_grad_norm (clipped), the others below it; weight decay on, so every parameter tensor has its own trust ratio."""
+    c, h, w, n = 4, 64, 64, 2
+    G, spec = build_generator(c, 41, F32)
+    G.train()
+    keys = orc.trainable_keys(spec)
+    named = dict(G.named_parameters())
+    assert list(named) == keys
+    opt = ph.get_optimizer(G.parameters(), "LAMB", 2e-3, 1e-6, 0.01)
+    P = {k: v.detach().cpu().clone() for k, v in named.items()}
+    ref = orc.Lamb(keys, lr=2e-3, eps=1e-6, weight_decay=0.01)
+    x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 78))
+    norms = []
+    for step, scale in enumerate((300.0, 1e-2, 1.0)):
+        opt.zero_grad()
+        loss = scale * (G(x) - y).abs().mean()
+        loss.backward()
+        grads = {k: v.grad.detach().cpu().clone() for k, v in named.items()}
+        norms.append(sum(float((g_.double() ** 2).sum()) for g_ in grads.values()) ** 0.5)
+        opt.step()
+        ref.step(P, grads)
+        torch.cuda.synchronize()
+        worst = max(rel_err(named[k].detach().cpu(), P[k]) for k in keys)
+        moved = max((named[k].detach().cpu() - spec_val).abs().max().item() for k, spec_val in
+                    ((k, orc.fill_state(spec, 41)[k]) for k in keys[:3]))
+        print(f"lamb step {step}: ||g|| {norms[-1]:.3e}, worst parameter rel err {worst:.2e}")
+        assert worst <= 2e-5 and moved > 0
+    assert norms[0] > 1.0 > norms[1], norms          # both sides of the clipping norm were exercised
+    st = opt.state_dict()["state"]
+    assert all(int(float(e["step"])) == 3 for e in st.values()) and len(st) == len(keys)
+
+
 def test_handover_notes_stay_inside_one_iteration():
     """ops.ToInternal / FromInternal hand-over (round 4): the NHWC copy of an unchanged boundary tensor is reused INSIDE one
     training iteration -- the generator's two forwards on one batch; the generator's output handed to the critic -- and never
