@@ -57,6 +57,8 @@ _SIGS = {
     "bg_conv2d_fwd_stats": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "bg_conv2d_bwd_data": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
     "bg_conv2d_bwd_weight": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bg_conv2d_bwd_weight_ws": [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "bg_conv2d_bwd_weight_ws_bytes": [C.POINTER(ConvDesc), c_vp],
     "bg_conv2d_bwd_weight_grouped": [c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp],
     "bg_conv2d_bwd_weight_grouped_taps": [C.POINTER(ConvDesc), c_vp, c_i32, c_vp],
     "bg_pack_conv_weights": [c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
@@ -253,7 +255,7 @@ def _alg_bytes(name, a) -> float:
     if name.startswith("bg_conv2d"):     # every operand once: activation in, activation out, weights
         d = a[0]
         es = _es(d.dtype)
-        wbytes = d.Cout * d.Cin * d.KH * d.KW * (4 if name == "bg_conv2d_bwd_weight" else es)
+        wbytes = d.Cout * d.Cin * d.KH * d.KW * (4 if name in ("bg_conv2d_bwd_weight", "bg_conv2d_bwd_weight_ws") else es)
         return float(d.N) * (d.H * d.W * d.Cin + d.Ho * d.Wo * d.Cout) * es + wbytes
     if name == "bg_dwconv3x3_bwd_fused":      # dy in, x in, da out
         d = a[0]
@@ -307,6 +309,21 @@ def host_call(name, *args):
         if "file corruption" in msg:
             raise IndexError(f"{name}: {msg}")
         raise RuntimeError(f"{name} failed ({rc}): {msg}")
+
+
+_WS_BYTES = {}
+
+
+def wgrad_ws_bytes(desc) -> int:
+    """Workspace of bg_conv2d_bwd_weight_ws for this descriptor (cached per shape)."""
+    key = (desc.dtype, desc.N, desc.H, desc.W, desc.Cin, desc.Ho, desc.Wo, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad, desc.dil,
+           desc.ldx, desc.ldy)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        out = C.c_int64(0)
+        host_call("bg_conv2d_bwd_weight_ws_bytes", C.byref(desc), C.cast(C.byref(out), c_vp))
+        n = _WS_BYTES[key] = int(out.value)
+    return n
 
 
 _FN = {}

@@ -674,6 +674,10 @@ struct WgradParams {
     int fold;                 // 1: the (tap, ci) pairs are ONE column dimension of RS*Ci (im2col'd x operand) -- the
                               // few-channel first layers, where a tap per tile would re-read dy nine times for
                               // 16 useful columns of 128
+    float* ws;                // not NULL: split s of tile t stores its 128 x 128 partial sums at ws[(s * tiles + t)] (plain
+                              // stores) and wgrad_ws_reduce_kernel adds them to dw in split order -- no atomics, and the
+                              // result does not depend on the order in which the workgroups finish
+    int splits;
 };
 
 constexpr int WG_PIX = 32;  // pixels per K-chunk
@@ -878,6 +882,19 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
 
     // accumulate: 32x32 accumulator layout: col = lane&31 (ci), row = (e&3)+8*(e>>2)+4*(lane>>5) (co)
     const int c32 = lane & 31, h = lane >> 5;
+    if (P.ws) {   // block-uniform: the whole tile as it stands, [co_local][ci_local], 128-byte runs per wave store
+        float* slice = P.ws + ((long long)split * tiles + (lin - split * tiles)) * (TILE * TILE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int col = wave_m * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, cil = wave_n * 64 + j * 32 + c32;
+                    slice[col * TILE + cil] = acc[i][j][e];
+                }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -899,6 +916,34 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgradParams P) {
 #endif
             }
         }
+}
+
+// dw += sum over splits (in split order) of the tiles wgrad_kernel left in the workspace: one thread per element of dW
+__global__ __launch_bounds__(256) void wgrad_ws_reduce_kernel(WgradParams P) {
+    const int RS = P.KH * P.KW;
+    const int tiles = P.fold ? P.tiles_co * P.tiles_ci : P.tiles_co * P.tiles_ci * RS;
+    const long long total = (long long)tiles * TILE * TILE;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i / (TILE * TILE)), r = (int)(i - (long long)t * (TILE * TILE));
+        const int col = r / TILE, cil = r - col * TILE;
+        int bid = t;
+        const int tile_ci = bid % P.tiles_ci;
+        bid /= P.tiles_ci;
+        int tap = P.fold ? 0 : bid % RS;
+        const int tile_co = P.fold ? bid : bid / RS;
+        const int co = tile_co * TILE + col;
+        int ci = tile_ci * TILE + cil;
+        if (P.fold) {
+            tap = ci / P.Ci;
+            ci -= tap * P.Ci;
+            if (tap >= RS) continue;
+        } else if (ci >= P.Ci) continue;
+        if (co >= P.Co) continue;
+        const float* src = P.ws + (long long)t * (TILE * TILE) + r;
+        float a = 0.f;
+        for (int s_ = 0; s_ < P.splits; ++s_) a += src[(long long)s_ * tiles * (TILE * TILE)];
+        P.dw[((long long)co * RS + tap) * P.Ci + ci] += a;
+    }
 }
 
 // ------------------------------------------------- gang weight gradient ----
@@ -1597,13 +1642,7 @@ extern "C" int bg_conv2d_bwd_data(const bg_conv_desc* d, const void* dy, const v
     return launch_gemm_conv<float>(P, (hipStream_t)stream);
 }
 
-extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
-                                    void* stream) {
-    int rc = check_conv_desc(d, "bg_conv2d_bwd_weight");
-    if (rc) return rc;
-    BG_CHECK_ARG(x && dy && dw && aligned16(x) && aligned16(dy), "bg_conv2d_bwd_weight: null/unaligned pointer");
-    WgradParams P{};
-    P.x = x; P.dy = dy; P.dw = dw;
+static int wgrad_plan(const bg_conv_desc* d, WgradParams& P, long long& tiles, long long& splits, const char* who) {
     P.N = d->N; P.H = d->H; P.W = d->W; P.Ho = d->Ho; P.Wo = d->Wo;
     P.Ci = d->Cin; P.Co = d->Cout; P.ldx = d->ldx; P.ldy = d->ldy;
     P.KH = d->KH; P.KW = d->KW; P.stride = d->stride; P.pad = d->pad; P.dil = d->dil;
@@ -1614,26 +1653,42 @@ extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const 
     const int vec_w = 16 / (int)dtype_size(d->dtype);
     P.fold = fold_ok && d->KH * d->KW > 1 && d->Cin <= 32 && d->Cin % vec_w == 0;
     if (P.fold) P.tiles_ci = (d->KH * d->KW * d->Cin + TILE - 1) / TILE;
-    const long long tiles = P.fold ? (long long)P.tiles_co * P.tiles_ci : (long long)P.tiles_co * P.tiles_ci * d->KH * d->KW;
-    // enough pixel splits to put ~1024 workgroups on the chip, each with >= 256 pixels
+    tiles = P.fold ? (long long)P.tiles_co * P.tiles_ci : (long long)P.tiles_co * P.tiles_ci * d->KH * d->KW;
     // Pixel splits: two 256-thread workgroups fit a CU (VGPRs), so one full wave of the chip
-    // is 512 workgroups.  Fill about one wave: more splits only add float-atomic traffic
-    // (every split adds a whole copy of dW), fewer leave CUs idle.
+    // is 512 workgroups.  Fill about one wave: more splits only add a whole copy of dW each
+    // (float atomics, or a workspace slice), fewer leave CUs idle.
     static const long long target_wgs = getenv("BGAMD_WGRAD_TARGET") ? atoll(getenv("BGAMD_WGRAD_TARGET")) : 512;
-    long long splits = tiles < 256 ? target_wgs / tiles : (2 * target_wgs + tiles - 1) / tiles;  // many tiles: balance the tail
+    splits = tiles < 256 ? target_wgs / tiles : (2 * target_wgs + tiles - 1) / tiles;  // many tiles: balance the tail
     const long long max_splits = (P.M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     P.pix_per_split = ((P.M + splits - 1) / splits + WG_PIX - 1) / WG_PIX * WG_PIX;
-    splits = (P.M + P.pix_per_split - 1) / P.pix_per_split;
-    BG_CHECK_ARG(tiles * splits <= 0x7fffffffLL, "bg_conv2d_bwd_weight: grid too large");
-    {
-        const long long es = dtype_size(d->dtype);
-        const long long xb = (((long long)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * es;
-        const long long yb = ((P.M - 1) * d->ldy + d->Cout) * es;
-        BG_CHECK_ARG(xb < (1LL << 31) && yb < (1LL << 31), "bg_conv2d_bwd_weight: operand larger than 2 GiB");
-        P.x_bytes = (int)xb;
-        P.dy_bytes = (int)yb;
+    splits = (P.M + P.pix_per_split - 1) / P.pix_per_split;     // every split owns pixels
+    BG_CHECK_ARG(tiles * splits <= 0x7fffffffLL, "%s: grid too large", who);
+    const long long es = dtype_size(d->dtype);
+    const long long xb = (((long long)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * es;
+    const long long yb = ((P.M - 1) * d->ldy + d->Cout) * es;
+    BG_CHECK_ARG(xb < (1LL << 31) && yb < (1LL << 31), "%s: operand larger than 2 GiB", who);
+    P.x_bytes = (int)xb;
+    P.dy_bytes = (int)yb;
+    P.splits = (int)splits;
+    return BG_OK;
+}
+
+static int wgrad_launch(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, float* ws, long long ws_bytes,
+                        void* stream, const char* who) {
+    int rc = check_conv_desc(d, who);
+    if (rc) return rc;
+    BG_CHECK_ARG(x && dy && dw && aligned16(x) && aligned16(dy), "%s: null/unaligned pointer", who);
+    WgradParams P{};
+    P.x = x; P.dy = dy; P.dw = dw;
+    long long tiles, splits;
+    rc = wgrad_plan(d, P, tiles, splits, who);
+    if (rc) return rc;
+    if (ws) {
+        BG_CHECK_ARG(aligned16(ws) && ws_bytes >= tiles * splits * (long long)(TILE * TILE * 4), "%s: workspace of %lld bytes, %lld needed",
+                     who, ws_bytes, tiles * splits * (long long)(TILE * TILE * 4));
+        P.ws = ws;
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == BG_BF16) {
@@ -1641,13 +1696,40 @@ extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const 
         hipLaunchKernelGGL((wgrad_kernel<bf16_t>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), sh, st, P);
     } else {
         const size_t sh = 2 * 2 * WG_PIX * (TILE * 4 + 64);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((wgrad_kernel<float>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), sh, st, P);
     }
     BG_CHECK_LAUNCH("wgrad_kernel");
+    if (P.ws) {
+        const long long total = tiles * TILE * TILE;
+        hipLaunchKernelGGL(wgrad_ws_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, P);
+        BG_CHECK_LAUNCH("wgrad_ws_reduce_kernel");
+    }
     if (dbias) return bg_colsum(d->dtype, dy, d->ldy, P.M, d->Cout, 1, 1.0f, dbias, stream);
     return BG_OK;
+}
+
+extern "C" int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                    void* stream) {
+    return wgrad_launch(d, x, dy, dw, dbias, nullptr, 0, stream, "bg_conv2d_bwd_weight");
+}
+
+extern "C" int bg_conv2d_bwd_weight_ws_bytes(const bg_conv_desc* d, int64_t* bytes) {
+    int rc = check_conv_desc(d, "bg_conv2d_bwd_weight_ws_bytes");
+    if (rc) return rc;
+    BG_CHECK_ARG(bytes != nullptr, "bg_conv2d_bwd_weight_ws_bytes: null result pointer");
+    WgradParams P{};
+    long long tiles, splits;
+    rc = wgrad_plan(d, P, tiles, splits, "bg_conv2d_bwd_weight_ws_bytes");
+    if (rc) return rc;
+    *bytes = tiles * splits * (long long)(TILE * TILE * 4);
+    return BG_OK;
+}
+
+extern "C" int bg_conv2d_bwd_weight_ws(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, float* ws,
+                                       int64_t ws_bytes, void* stream) {
+    BG_CHECK_ARG(ws != nullptr, "bg_conv2d_bwd_weight_ws: null workspace");
+    return wgrad_launch(d, x, dy, dw, dbias, ws, ws_bytes, stream, "bg_conv2d_bwd_weight_ws");
 }
 
 #ifdef BG_STAMPS

@@ -117,6 +117,24 @@ _WG_ENABLED = _os.environ.get("BGAMD_WGRAD_STREAM", "0") != "0" and not _os.envi
 _WG_MIN_ELEMS = int(_os.environ.get("BGAMD_WGRAD_STREAM_MIN", str(8 << 20)))
 
 
+# Per-layer weight gradients (the layers the gang kernel does not take) CAN go through the workspace form: no float atomics,
+# bit-reproducible (BGAMD_WGRAD_WS=1).  Not the default: the atomics are not what these launches wait for -- 3 x 3 128 -> 128
+# at 576 x 384 runs 866 -> 836 us, but the HBM-bound 1 x 1 layers pay for writing and re-reading 32 MB of split tiles
+# (168 -> 277 us; scripts/bench_wgrad_ws.py, profiles/r04_bench_wgrad_ws.txt).
+_WG_WS = _os.environ.get("BGAMD_WGRAD_WS", "0") != "0"
+
+
+def _wgrad_layer(desc, x, g, dw_ptr, dbias=None, swap=False):
+    """(entry point, arguments, tensors to keep alive) of one layer's weight gradient; swap: transposed convolutions hand
+    their operands over with the roles exchanged."""
+    a, b = (g, x) if swap else (x, g)
+    if not _WG_WS:
+        return "bg_conv2d_bwd_weight", (desc, a.data_ptr(), b.data_ptr(), dw_ptr, dbias), (x, g)
+    nbytes = L.wgrad_ws_bytes(desc)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    return "bg_conv2d_bwd_weight_ws", (desc, a.data_ptr(), b.data_ptr(), dw_ptr, dbias, ws.data_ptr(), nbytes), (x, g, ws)
+
+
 def _wg_register(key):
     """One end-of-backward callback per device and backward pass.  A pass is identified by the autograd engine's graph
     task id: if an earlier pass raised, its callback never ran -- its entry here is stale, the groups it queued are
@@ -133,7 +151,7 @@ def wgrad_call(dev, tensors, name, *args):
     """Launch a weight-gradient entry point on the second stream (after everything enqueued so far on the
     caller's stream); `tensors` are the operands whose memory must outlive that launch."""
     if (not _WG_ENABLED or L.PROFILE is not None or torch._C._current_graph_task_id() < 0
-            or max(t.numel() for t in tensors) < _WG_MIN_ELEMS):
+            or max(t.numel() for t in tensors[:2]) < _WG_MIN_ELEMS):
         L.call(name, *args)   # the profile step times ONE kernel per event pair; outside a backward pass nothing would join
         return
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -199,7 +217,8 @@ def wgrad_group_add(dev, x, g, dw_ptr, rows, cin, cout, desc):
         # shapes the gang kernel never takes (mostly padding in 256 x 256 tiles: the 128-channel entry-flow layers, 450 MB
         # of gradient each at 1152 x 768, batch 8) go out now, on the side stream under the data-gradient chain, instead
         # of holding their operands until the pass ends; so does a call from outside a backward pass (no callback to flush)
-        wgrad_call(dev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dw_ptr, None)
+        name, args, keep = _wgrad_layer(desc, x, g, dw_ptr)
+        wgrad_call(dev, keep, name, *args)
         return
     _wg_register(key)
     sig = (rows, cin, cout, ld_of(x), ld_of(g))
@@ -253,10 +272,12 @@ def wgrad_group_flush(key, only_sig=None):
                 g.record_stream(side)
         if not _gang_pays(len(jobs), cin, cout, rows):
             for x, g, dwp, desc in jobs:
+                name, args, keep = _wgrad_layer(desc, x, g, dwp)
                 if use_side:
-                    L.call_on(raw, "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dwp, None)
+                    keep[-1].record_stream(side)
+                    L.call_on(raw, name, *args)
                 else:
-                    L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), dwp, None)
+                    L.call(name, *args)
             continue
         # the addresses are read on the host during the call and travel in the kernel arguments: no table in device memory
         tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), dwp, 0] for x, g, dwp, _ in jobs], dtype=torch.int64)
@@ -683,7 +704,8 @@ class Conv2dFn(torch.autograd.Function):
                 tbl = torch.tensor([[x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), 0]], dtype=torch.int64)
                 wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight_grouped_taps", desc, tbl.data_ptr(), 1)
             else:
-                wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, x.data_ptr(), g.data_ptr(), arena.grad_ptr(wslot), dbias)
+                name, args, keep = _wgrad_layer(desc, x, g, arena.grad_ptr(wslot), dbias)
+                wgrad_call(xdev, keep, name, *args)
         return dx, None, None, None, None, None, None, None, None, None
 
 
@@ -727,7 +749,8 @@ class ConvTranspose2dFn(torch.autograd.Function):
             (x,) = ctx.saved_tensors
             arena.ensure_grad(wslot)
             desc = L.ConvDesc(L.dt(xdtype), n, ho, wo, cp, h, w, kp, kh, kw, stride, pad, 1, ld_of(g), ld_of(x))
-            wgrad_call(xdev, (x, g), "bg_conv2d_bwd_weight", desc, g.data_ptr(), x.data_ptr(), arena.grad_ptr(wslot), None)
+            name, args, keep = _wgrad_layer(desc, x, g, arena.grad_ptr(wslot), None, swap=True)
+            wgrad_call(xdev, keep, name, *args)
         return dx, None, None, None, None, None, None
 
 

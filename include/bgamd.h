@@ -105,6 +105,14 @@ int bg_conv2d_fwd_splitk(const bg_conv_desc* d, const void* x, const void* w, fl
 int bg_conv2d_bwd_data_splitk(const bg_conv_desc* d, const void* dy, const void* wt, float* ws, int32_t splits, void* stream);
 int bg_splitk_reduce(int32_t dtype, const float* ws, int32_t splits, int64_t rows, int32_t C, void* y, int32_t ldy, void* stream);
 int bg_conv2d_bwd_weight(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* stream);
+/* The same weight gradient WITHOUT float atomics: every pixel split stores its 128 x 128 partial tiles into `ws` (plain
+ * stores) and a second launch adds them to dW in split order -- each dW element is written by one thread, so the result does
+ * not depend on workgroup scheduling (bit-reproducible).  Measured against the atomics: equal on the MFMA-bound 3 x 3 layers,
+ * 0.6-0.9x on HBM-bound 1 x 1 layers (the split tiles are written and read back), so the host mirror keeps it opt-in.
+ * bg_conv2d_bwd_weight_ws_bytes: the workspace this descriptor needs (tiles x splits x 64 KiB; a few tens of MB). */
+int bg_conv2d_bwd_weight_ws_bytes(const bg_conv_desc* d, int64_t* bytes);
+int bg_conv2d_bwd_weight_ws(const bg_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, float* ws,
+                            int64_t ws_bytes, void* stream);
 /* Weight gradients of n_layers POINTWISE (1x1, stride 1) convolutions of one shape in one launch (bf16 operands):
  * dw_l[Cout][Cin] (fp32) += dy_l^T x_l over the M pixels, for l < n_layers.  tbl (HOST memory, read during the call):
  * n_layers rows of 4 int64 {x_l, dy_l, dw_l, 0} device addresses -- they travel in the kernel arguments.  The (layer, pixel) space is cut into equal ranges walked by gangs of one

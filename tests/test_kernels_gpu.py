@@ -430,6 +430,37 @@ def test_losses():
     assert_close(gp.cpu(), ((g.norm(2, dim=1) - 1) ** 2).mean().reshape(1), 1e-5, "gp")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,dil", [(2, 40, 36, 128, 128, 3, 1, 1), (3, 33, 20, 24, 40, 1, 1, 1), (2, 64, 48, 16, 128, 3, 2, 1),
+                                                         (2, 24, 24, 136, 264, 3, 1, 2), (1, 16, 16, 728, 728, 1, 1, 1)])
+def test_conv_wgrad_workspace_form_is_the_atomic_one_and_reproducible(dtype, n, h, w, cin, cout, k, stride, dil):
+    """bg_conv2d_bwd_weight_ws (split tiles in a workspace, added in split order) == bg_conv2d_bwd_weight (float atomics) to
+    summation order, accumulates into dW like it, and two runs are bit-identical -- taps as tiles, the folded few-channel
+    layout (Cin 16, stride 2), channel counts off the tile size, a dilated layer, the 16 x 16 maps."""
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    pad = dil * (k - 1) // 2
+    g_ = torch.Generator().manual_seed(5)
+    x = torch.randn(n, h, w, cin, generator=g_).to(dtype).to(DEV)
+    gy = (torch.randn(n, ho, wo, cout, generator=g_) * 0.1).to(dtype).to(DEV)
+    desc = L.ConvDesc(L.dt(dtype), n, h, w, cin, ho, wo, cout, k, k, stride, pad, dil, cin, cout)
+    nb = L.wgrad_ws_bytes(desc)
+    ws = torch.full((nb,), 0x7f, dtype=torch.uint8, device=DEV)      # stale bytes: every slice the second pass reads must have been written
+    base = torch.randn(cout, k, k, cin, generator=g_).to(DEV)
+    outs = []
+    for form in ("atomic", "ws", "ws"):
+        dw = base.clone()
+        if form == "atomic":
+            L.call("bg_conv2d_bwd_weight", desc, x.data_ptr(), gy.data_ptr(), dw.data_ptr(), None)
+        else:
+            L.call("bg_conv2d_bwd_weight_ws", desc, x.data_ptr(), gy.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], outs[2])
+    assert_close((outs[1] - base).cpu(), (outs[0] - base).cpu(), 5e-6 if dtype == torch.float32 else 2e-5, "workspace vs atomic")
+    with pytest.raises(RuntimeError, match="workspace"):
+        L.call("bg_conv2d_bwd_weight_ws", desc, x.data_ptr(), gy.data_ptr(), outs[0].data_ptr(), None, ws.data_ptr(), nb - 16)
+
+
 def test_adam_matches_torch():
     n = 1000
     p0, g1, g2 = torch.randn(n), torch.randn(n) * 1e-3, torch.randn(n) * 1e-3
