@@ -27,8 +27,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 echo c5 fp8 kernel-trace done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_bench.json 2> $O/prof_bench.err || { tail -5 $O/prof_bench.err; exit 1; }
 echo kernel-trace done
-BGAMD_NO_WGRAD_STREAM=1 BGAMD_NO_SIDE_STREAM=1 BGAMD_NO_G_PREFETCH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_single.json 2> $O/prof_single.err || { tail -5 $O/prof_single.err; exit 1; }
+BGAMD_NO_SIDE_STREAM=1 BGAMD_NO_G_PREFETCH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_single.json 2> $O/prof_single.err || { tail -5 $O/prof_single.err; exit 1; }
 echo single-stream kernel-trace done
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -o bench -- python3 $R/bench.py --height 256 --width 256 --steps 10 --warmup 6 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_c2.json 2> $O/prof_c2.err || { tail -5 $O/prof_c2.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o bench -- python3 $R/bench.py --loss wgan-gp --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-host-floor > $O/prof_c4.json 2> $O/prof_c4.err || { tail -5 $O/prof_c4.err; exit 1; }
+echo c2 / c4 kernel-trace done
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-host-floor > /dev/null 2> $O/pmc_fetch.err || { tail -5 $O/pmc_fetch.err; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-host-floor > /dev/null 2> $O/pmc_write.err || { tail -5 $O/pmc_write.err; exit 1; }
 echo pmc traffic done
@@ -43,5 +46,7 @@ python scripts/pmc_sq_summary.py $S $O/pmc_sq.json
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cp $(find $O/prof_single -name "*kernel_stats.csv" | head -1) $O/kernel_stats_single_stream.csv
 cp $(find $O/prof_c5 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c5_fp8.csv
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/prof $O/prof_single $O/prof_c5
+cp $(find $O/prof_c2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c2.csv
+cp $(find $O/prof_c4 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_c4.csv
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/prof $O/prof_single $O/prof_c5 $O/prof_c2 $O/prof_c4
 ls -la $O
