@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(EwBwdParams P) 
 template <typename T, int SIGN>
 void launch_bwd_apply_s(const EwBwdParams& P, const dim3 grid, const dim3 block, bool useB, hipStream_t st) {
     const size_t lds = (size_t)5 * P.tx * Elem<T>::VEC * sizeof(float);
-    if constexpr (sizeof(T) == 2 && SIGN != 0) {
+    if constexpr (sizeof(T) == 2) {
         if (P.dxq) {   // (the entry point admits the fp8 copy only with the training-mode terms)
             if (P.dres) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, true, true, true>), grid, block, lds, st, P);
             else hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, SIGN, false, true, true>), grid, block, lds, st, P);
@@ -1049,9 +1049,9 @@ extern "C" int bg_norm_act_bwd_apply_stats_q8(int32_t dtype, const void* dy, int
                                               int32_t train, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
                                               int32_t lddres, int64_t rows, int32_t C, int32_t groups, int32_t act, void* dxq,
                                               int32_t lddxq, const int32_t* q_exp, uint32_t* q_amax, void* stream) {
-    BG_CHECK_ARG(dtype == BG_BF16 && train && act && dx && dxq && q_exp && q_amax && aligned16(dxq) && lddxq % 16 == 0 &&
+    BG_CHECK_ARG(dtype == BG_BF16 && train && dx && dxq && q_exp && q_amax && aligned16(dxq) && lddxq % 16 == 0 &&
                      lddxq >= (C + 15) / 16 * 16,
-                 "bg_norm_act_bwd_apply_stats_q8: bf16, training mode, an activation, dx and a 16-byte-aligned fp8 buffer of "
+                 "bg_norm_act_bwd_apply_stats_q8: bf16, training mode, dx and a 16-byte-aligned fp8 buffer of "
                  "pixel stride >= C rounded up to 16");
     return bwd_apply_stats_impl(dtype, dy, lddy, y, ldy, x, ldx, s1, s2, gamma, beta, mean, rstd, train, dgamma, dbeta, dx, lddx,
                                 dres, lddres, rows, C, groups, act, dxq, lddxq, q_exp, q_amax, stream);

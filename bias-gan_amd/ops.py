@@ -1017,7 +1017,7 @@ class NormActFn(torch.autograd.Function):
         ctx.meta = (arena, gslot, bslot, kind, use_batch_stats, int(act), groups, res is not None)
         ctx.tail = None
         if (offer_tail and _FORK_FUSED and kind == "batch" and use_batch_stats and x.dtype == torch.bfloat16
-                and ctx.needs_input_grad[0] and ctx.q_site is None and not getattr(arena, "fp8", False)):
+                and ctx.needs_input_grad[0]):
             ctx.tail = y._bg_tail = NormTail(x, mean, rstd, groups, int(act), y)
         return y
 
@@ -1047,9 +1047,12 @@ class NormActFn(torch.autograd.Function):
                     arena.ensure_grad(gslot)
                     arena.ensure_grad(bslot)
                     dg, db = arena.grad_ptr(gslot), arena.grad_ptr(bslot)
-                L.call("bg_norm_act_bwd_apply_stats", dt, g.data_ptr(), ld_of(g), None, 0, x.data_ptr(), ld_of(x),
-                       s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot), arena.master_ptr(bslot), mean.data_ptr(),
-                       rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), None, 0, rows, c, groups, 0)
+                args = (dt, g.data_ptr(), ld_of(g), None, 0, x.data_ptr(), ld_of(x),
+                        s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot), arena.master_ptr(bslot), mean.data_ptr(),
+                        rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), None, 0, rows, c, groups, 0)
+                # fp8 operand path: dx still leaves with its e5m2 copy for the data-gradient GEMM of the convolution that made x
+                # (same rule as below: the layers whose BatchNorm carries the activation)
+                _apply_stats_maybe_q8(ctx.q_site if act else None, dx, args, n, h, w, c)
             return (dx, g if need_res else None) + (None,) * 16
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None

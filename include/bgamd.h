@@ -164,7 +164,7 @@ int bg_pack_conv_weights(int32_t dtype, const void* src, void* dst_krsc, void* d
 /* bg_norm_act_bwd_apply_stats that ALSO writes dx as e5m2 bytes for the data-gradient GEMM of the convolution that
  * produced x (bg_quant_fp8's contract with fmt = BG_FP8_E5M2 on the dx values as stored; dxq: [rows][lddxq] bytes, C
  * rounded up to 16 with zero lanes; *q_amax updated): one quantisation pass saved per layer.  bf16, training mode,
- * with an activation, dx required. */
+ * dx required (act may be 0: the apply pass behind a fused fork backward, whose gradient already carries act'). */
 int bg_norm_act_bwd_apply_stats_q8(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                                    int32_t ldx, const double* s1, const double* s2, const float* gamma, const float* beta,
                                    const float* mean, const float* rstd, int32_t train, float* dgamma, float* dbeta, void* dx,
