@@ -1051,8 +1051,7 @@ class NormActFn(torch.autograd.Function):
                         s[0].data_ptr(), s[1].data_ptr(), arena.master_ptr(gslot), arena.master_ptr(bslot), mean.data_ptr(),
                         rstd.data_ptr(), 1, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), None, 0, rows, c, groups, 0)
                 # fp8 operand path: dx still leaves with its e5m2 copy for the data-gradient GEMM of the convolution that made x
-                # (same rule as below: the layers whose BatchNorm carries the activation)
-                _apply_stats_maybe_q8(ctx.q_site if act else None, dx, args, n, h, w, c)
+                _apply_stats_maybe_q8(ctx.q_site, dx, args, n, h, w, c)
             return (dx, g if need_res else None) + (None,) * 16
         dx = new_act(n, h, w, c, x.dtype, dev) if need_dx else None
         dres = new_act(n, h, w, c, x.dtype, dev) if need_res else None
@@ -1084,7 +1083,7 @@ class NormActFn(torch.autograd.Function):
                     s[0].data_ptr(), s[1].data_ptr(), gptr, bptr, mean.data_ptr(), rstd.data_ptr(),
                     1 if batch_stats else 0, dg, db, L.ptr(dx), 0 if dx is None else ld_of(dx), L.ptr(dres),
                     0 if dres is None else ld_of(dres), rows, c, groups, act)
-            _apply_stats_maybe_q8(ctx.q_site if (batch_stats and act) else None, dx, args, *x.shape)
+            _apply_stats_maybe_q8(ctx.q_site if batch_stats else None, dx, args, *x.shape)
         elif need_res:
             L.call("bg_norm_act_bwd_apply", dt, g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), None, 0, None, None, None, None,
                    0, dres.data_ptr(), ld_of(dres), rows, c, groups, act)
