@@ -103,15 +103,30 @@ __device__ __forceinline__ float pix_loss_grad(int kind, float d) {
     return kind == 0 ? sgn : (kind == 1 ? (fabsf(d) < 1.f ? d : sgn) : 2.f * d);
 }
 
-__global__ void l1_fwd_kernel(int kind, const float* p, const float* t, const float* w, long long n, float inv_norm,
-                              float* loss) {
+// One atomic per BLOCK: 8 192 per-wave atomics onto the one loss word serialised at ~12 ns each -- 100 us of the 117 us this
+// kernel took on the 256 x 256 fields (67 MB) and of its 266 us at 1152 x 768; 16-byte loads where the tensors allow.
+__global__ __launch_bounds__(256) void l1_fwd_kernel(int kind, const float* p, const float* t, const float* w, long long n, float inv_norm,
+                                                     float* loss) {
     float acc = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    const bool v4 = ((((uintptr_t)p | (uintptr_t)t | (uintptr_t)w) & 15) == 0);
+    const long long n4 = v4 ? n / 4 : 0;
+    for (long long i = tid0; i < n4; i += nth) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[i], b = reinterpret_cast<const f32x4*>(t)[i];
+        f32x4 ww = {1.f, 1.f, 1.f, 1.f};
+        if (w) ww = reinterpret_cast<const f32x4*>(w)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(pix_loss(kind, a[e] - b[e]), ww[e], acc);
+    }
+    for (long long i = n4 * 4 + tid0; i < n; i += nth) {
         const float a = pix_loss(kind, p[i] - t[i]);
         acc += w ? a * w[i] : a;
     }
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_norm);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_norm);
 }
 
 __global__ void l1_bwd_kernel(int kind, const float* p, const float* t, const float* w, long long n, float inv_norm,
