@@ -328,10 +328,11 @@ __global__ __launch_bounds__(256) void dw_ring_kernel(DwParams P) {
     const int n = band / P.bands, b = band - n * P.bands;
     float* ptab = reinterpret_cast<float*>(dw_smem + RING_LDS);  // [2][C] scale, shift (PRE with pre_sum)
     // Order of the prologue: the ring's first rows are requested BEFORE the BatchNorm coefficients are formed.  The
-    // coefficient table needs a round trip of its own (the producer's fp64 sums) and the DMA does not depend on it; issued
-    // one after the other the two latencies added up -- 11.1 us against 6.6 for the same launch without the table on the
-    // 16 x 16 maps of the 256 x 256 configuration (rocprofv3 kernel trace).  Threads beyond the tile's items request
-    // nothing (out-of-range offsets) and leave after the table's barrier.
+    // coefficient table needs a round trip of its own (the producer's fp64 sums) and the DMA does not depend on it, so the
+    // two latencies overlap instead of adding up.  Worth 0.3 % of the step (same-box A/B of two builds, scripts/gpu_ab_lib.sh);
+    // what the prologue costs besides is its arithmetic: 4.7 us plain, 6.5 with scale / shift tables, 7.5 with the tables
+    // derived here, on 16 x 16 maps with hot operands (scripts/bench_dw_small.py).  Threads beyond the tile's items
+    // request nothing (out-of-range offsets) and leave after the table's barrier.
     const bool active = idx < (unsigned)P.items;
     const unsigned wq = idx / cv;
     const int c = (int)(idx - wq * cv) * VEC;
