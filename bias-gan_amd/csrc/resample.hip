@@ -294,6 +294,85 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_vec4_kernel(const T* src, in
     }
 }
 
+// bf16 NHWC rows of 16 / 32 / 64 bytes (8 * CPP channels, dense) <-> fp32 NCHW through LDS: a block moves 1 024 pixels; the
+// NHWC side is touched in whole consecutive kilobytes per wave instruction (the four-pixel form above reads / writes 16 bytes
+// of every 128-byte line per instruction: 2.2-3.3 TB/s on the 1152 x 768 x 16 fields), the NCHW side in float4 per plane.
+// Chunk g of the tile (16 bytes; g = pixel * CPP + chunk) sits at 16 * (8 * (g / 8) + ((g % 8) ^ ((g / 8) & 7))): linear
+// writes and the transposed reads (lane stride 4 * CPP chunks) are both conflict-free for CPP <= 2, 2-way for CPP = 4.
+constexpr int LT_PIX = 1024;
+__device__ __forceinline__ int lt_swz(int g) { return ((g >> 3) << 3) + ((g & 7) ^ ((g >> 3) & 7)); }
+
+template <int CPP>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_lds_kernel(const bf16_t* src, float* dst, int C, int HW) {
+    __shared__ u32x4 tile[LT_PIX * CPP];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * LT_PIX;
+    const int npix = (int)min((long long)LT_PIX, (long long)HW - p0);
+    const u32x4* s = reinterpret_cast<const u32x4*>(src + ((long long)n * HW + p0) * (8 * CPP));
+#pragma unroll
+    for (int k = 0; k < 4 * CPP; ++k) {
+        const int g = k * 256 + tid;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (g < npix * CPP) v = __builtin_nontemporal_load(s + g);
+        tile[lt_swz(g)] = v;
+    }
+    __syncthreads();
+    const int p = tid * 4;
+    if (p >= npix) return;                      // HW % 4 == 0: a thread's four pixels are all inside or all outside
+    float* d = dst + (long long)n * C * HW + p0 + p;
+#pragma unroll
+    for (int cc = 0; cc < CPP; ++cc) {
+        u32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tile[lt_swz((p + q) * CPP + cc)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (cc * 8 + e >= C) break;
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned w = v[q][e >> 1];
+                o[q] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(d + (long long)(cc * 8 + e) * HW));
+        }
+    }
+}
+
+template <int CPP>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_lds_kernel(const float* src, bf16_t* dst, int C, int HW) {
+    __shared__ u32x4 tile[LT_PIX * CPP];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * LT_PIX;
+    const int npix = (int)min((long long)LT_PIX, (long long)HW - p0);
+    const int p = tid * 4;
+    if (p < npix) {
+        const float* sp = src + (long long)n * C * HW + p0 + p;
+#pragma unroll
+        for (int cc = 0; cc < CPP; ++cc) {
+            f32x4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = (cc * 8 + e < C) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + (long long)(cc * 8 + e) * HW))
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Chunk<bf16_t> o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.set(e, v[e][q]);
+                tile[lt_swz((p + q) * CPP + cc)] = __builtin_bit_cast(u32x4, o.v);
+            }
+        }
+    }
+    __syncthreads();
+    u32x4* d = reinterpret_cast<u32x4*>(dst + ((long long)n * HW + p0) * (8 * CPP));
+#pragma unroll
+    for (int k = 0; k < 4 * CPP; ++k) {
+        const int g = k * 256 + tid;
+        if (g < npix * CPP) d[g] = tile[lt_swz(g)];
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* src, int lds, float* dst, int N, int C, int HW) {
     const long long total = (long long)N * HW;
@@ -442,12 +521,26 @@ extern "C" int bg_axpy_rows(int32_t dtype, const void* x, int32_t ldx, void* y, 
     return BG_OK;
 }
 
+static bool lt_on() {   // BGAMD_LAYOUT_LDS=0: the four-pixel register forms (A/B)
+    static const bool on = !(getenv("BGAMD_LAYOUT_LDS") && atoi(getenv("BGAMD_LAYOUT_LDS")) == 0);
+    return on;
+}
+
 extern "C" int bg_nchw_to_nhwc(int32_t dst_dtype, const float* src, void* dst, int32_t N, int32_t C, int32_t HW,
                                int32_t Cp, int32_t ldd, void* stream) {
     BG_CHECK_ARG(dtype_ok(dst_dtype) && src && dst && N > 0 && C > 0 && HW > 0 && Cp >= C && ldd >= Cp,
                  "bg_nchw_to_nhwc: bad args");
     const long long total = (long long)N * HW;
     const int vec = dtype_vec(dst_dtype);
+    if (lt_on() && dst_dtype == BG_BF16 && aligned16(dst) && aligned16(src) && ldd == Cp && (Cp == 8 || Cp == 16 || Cp == 32) &&
+        N <= 65535 && HW % 4 == 0) {
+        const dim3 grid((HW + LT_PIX - 1) / LT_PIX, N);
+        if (Cp == 8) hipLaunchKernelGGL((nchw_to_nhwc_lds_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, C, HW);
+        else if (Cp == 16) hipLaunchKernelGGL((nchw_to_nhwc_lds_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, C, HW);
+        else hipLaunchKernelGGL((nchw_to_nhwc_lds_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, C, HW);
+        BG_CHECK_LAUNCH("nchw_to_nhwc_lds_kernel");
+        return BG_OK;
+    }
     if (aligned16(dst) && aligned16(src) && Cp % vec == 0 && ldd % vec == 0 && N <= 65535 && HW % 4 == 0) {
         BG_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_vec4_kernel<T>), dim3((HW / 4 + 255) / 256, N), dim3(256),
                                                            0, (hipStream_t)stream, src, (T*)dst, C, HW, Cp, ldd));
@@ -472,6 +565,18 @@ extern "C" int bg_nhwc_to_nchw(int32_t src_dtype, const void* src, int32_t lds, 
     const long long total = (long long)N * HW;
     const int vec = dtype_vec(src_dtype);
     // the vector form reads whole 16-byte chunks: the row must hold them (lds >= C rounded up)
+    // (towards NCHW the staged form only pays on 64-byte rows: 16 channels 119 against 108 us at 8 x 1152 x 768, 32 channels 521
+    // against 686 us at 4 x 2304 x 1536; towards NHWC it pays everywhere: 103 against 144, 498 against 831; scripts/bench_layout.py)
+    static const bool lt_all = getenv("BGAMD_LAYOUT_LDS") && atoi(getenv("BGAMD_LAYOUT_LDS")) == 2;
+    if (lt_on() && src_dtype == BG_BF16 && aligned16(src) && aligned16(dst) && (lds == 32 || (lt_all && (lds == 8 || lds == 16))) && C <= lds &&
+        N <= 65535 && HW % 4 == 0) {
+        const dim3 grid((HW + LT_PIX - 1) / LT_PIX, N);
+        if (lds == 8) hipLaunchKernelGGL((nhwc_to_nchw_lds_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, C, HW);
+        else if (lds == 16) hipLaunchKernelGGL((nhwc_to_nchw_lds_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, C, HW);
+        else hipLaunchKernelGGL((nhwc_to_nchw_lds_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, C, HW);
+        BG_CHECK_LAUNCH("nhwc_to_nchw_lds_kernel");
+        return BG_OK;
+    }
     if (aligned16(src) && aligned16(dst) && lds % vec == 0 && lds >= (C + vec - 1) / vec * vec && N <= 65535 && HW % 4 == 0) {
         BG_DISPATCH_DTYPE(src_dtype, T, hipLaunchKernelGGL((nhwc_to_nchw_vec4_kernel<T>), dim3((HW / 4 + 255) / 256, N), dim3(256),
                                                            0, (hipStream_t)stream, (const T*)src, lds, dst, C, HW));

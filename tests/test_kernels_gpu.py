@@ -504,10 +504,11 @@ def test_adam_with_device_scalars_matches_launch_arguments():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("c,cp,ld", [(16, 16, 32), (5, 8, 8), (20, 24, 40)])
+@pytest.mark.parametrize("c,cp,ld", [(16, 16, 32), (5, 8, 8), (20, 24, 40), (16, 16, 16), (13, 16, 16), (32, 32, 32), (27, 32, 32), (8, 8, 8)])
 def test_layout_four_pixel_form(dtype, c, cp, ld):
     """HW % 4 == 0: the float4 forms of bg_nchw_to_nhwc / bg_nhwc_to_nchw (pad lanes zeroed, the row tail beyond Cp
-    untouched, exact round trip)."""
+    untouched, exact round trip); dense bf16 rows of 8 / 16 / 32 channels take the LDS-staged form (1 024-pixel tiles: the
+    12 x 172 image is two tiles and a tail of 16 pixels)."""
     n, h, w = 3, 12, 43 * 4
     xs = rnd((n, c, h, w), 41, torch.float32).to(DEV)
     nh = torch.full((n, h, w, ld), 3.0, dtype=dtype, device=DEV)
