@@ -50,11 +50,15 @@ struct DwParams {
 template <typename T>
 __device__ __forceinline__ void dw_pre_apply(Chunk<T>& v, const float* sc, const float* sh, float slope, bool keep) {
     constexpr int VEC = Elem<T>::VEC;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
     Chunk<T> o;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const float z = fmaf(v.get(e), sc[e], sh[e]);
-        o.set(e, fmaxf(z, slope * z));
+    for (int e = 0; e < VEC; e += 2) {   // pairs: v_pk_fma_f32 / v_pk_mul_f32 (the same fused multiply-add per element)
+        const f32x2 x = {v.get(e), v.get(e + 1)}, s = {sc[e], sc[e + 1]}, h = {sh[e], sh[e + 1]};
+        const f32x2 z = __builtin_elementwise_fma(x, s, h);
+        const f32x2 zs = z * slope;
+        o.set(e, fmaxf(z[0], zs[0]));
+        o.set(e + 1, fmaxf(z[1], zs[1]));
     }
     if (!keep) o.zero();
     v = o;
