@@ -175,6 +175,54 @@ def build_discriminator(c, h, w, seed, dtype, norm=nn.BatchNorm2d, kind="batch")
     return D.to(DEV), spec
 
 
+def test_generator_gradients_agree_across_schedules(monkeypatch):
+    """What test_step_schedules_agree cannot see (one Adam step moves every weight by +-lr whatever its gradient): the
+    GRADIENT arenas themselves, read just before each optimiser step, under the trainer's scheduling options against the
+    plain sequential schedule.  D's learning rate is 0, so the generator's gradient is comparable as well.  With the
+    generator-ahead forward on the side stream the generator's backward nodes run on that stream and its grouped weight
+    gradients are issued from the end-of-backward callback on the caller's stream (ordered by the engine's leaf-stream
+    synchronisation): its gradient must equal the plain schedule's to summation order -- a stale or early read would not.
+    The batched critic pass differs from two separate passes by the conditioning of BatchNorm over 32 values per channel and
+    half (1e-3 here; the same amplification test_unet3d_vs_reference_golden documents), not by schedule."""
+    monkeypatch.setenv("BGAMD_STEP_GRAPH", "0")
+    c, h, w, n = 4, 64, 64, 2
+
+    def run(batched, ahead):
+        G, _ = build_generator(c, 31, F32)
+        D, _ = build_discriminator(c, h, w, 32, F32)
+        G.train(), D.train()
+        crit = losses.GANLoss("ModifiedMinMax", n, torch.device(DEV))
+        g_opt = ph.get_optimizer(G.parameters(), "Adam", 1e-4, 1e-8, 1e-5)
+        d_opt = ph.get_optimizer(D.parameters(), "Adam", 0.0, 1e-8, 0.0)
+        tr = GANTrainer(G, D, g_opt, d_opt, crit, losses.L1Loss())
+        tr._batched_d, tr._g_ahead_ok = batched, ahead
+        if not (batched or ahead):
+            tr._side = None
+        seen = {}
+        for tag, net, opt in (("g", G, g_opt), ("d", D, d_opt)):
+            orig = opt.step
+            def rec(*a, _o=orig, _t=tag, _n=net, **k):
+                torch.cuda.synchronize()
+                seen.setdefault(_t, _n.arena().grad.double().clone().cpu())
+                return _o(*a, **k)
+            monkeypatch.setattr(opt, "step", rec)
+        torch.manual_seed(3)
+        x, y = (t.to(DEV) for t in orc.synthetic_fields(n, c, h, w, 77))
+        tr.step(x, y, labels=crit.draw_labels())
+        torch.cuda.synchronize()
+        return seen
+
+    base = run(False, False)
+    noise = max(rel_err(run(False, False)[k], base[k]) for k in ("g", "d"))     # two runs of the plain schedule: atomics' order
+    ahead = run(False, True)
+    both = run(True, True)
+    print(f"plain twice {noise:.1e}; ahead: g {rel_err(ahead['g'], base['g']):.1e} d {rel_err(ahead['d'], base['d']):.1e}; "
+          f"batched + ahead: g {rel_err(both['g'], base['g']):.1e} d {rel_err(both['d'], base['d']):.1e}")
+    assert noise <= 5e-5
+    assert rel_err(ahead["g"], base["g"]) <= 5e-5 and rel_err(ahead["d"], base["d"]) <= 5e-5
+    assert rel_err(both["g"], base["g"]) <= 5e-5 and rel_err(both["d"], base["d"]) <= 2e-2
+
+
 def test_fused_lamb_matches_the_oracle_restatement():
     """utils/parsing_helpers.py:13-14 (optimizer 'LAMB' = apex FusedLAMB): bg_sumsq_f32 + bg_lamb_stage1 + bg_lamb_stage2 over
     the generator's arena against oracle.Lamb fed the SAME gradients, three steps: the first with the global norm above
