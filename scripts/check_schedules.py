@@ -12,7 +12,7 @@ from bias_gan_amd.utils import losses, parsing_helpers as ph
 from oracle import gan_oracle as orc
 
 DEV = "cuda:0"
-c, h, w, n = 4, 64, 64, 2
+c, h, w, n = 4, int(os.environ.get("HW", "64")), int(os.environ.get("HW", "64")), int(os.environ.get("NB", "2"))
 
 def run(batched, ahead):
     with contextlib.redirect_stdout(io.StringIO()):
